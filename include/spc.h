@@ -1,0 +1,163 @@
+/*
+ * spc.h -- C ABI of the MI355X-native batched superparameterization coupling step.
+ *
+ * The reference (CloudResolvingClimateModeling/sp-coupler) is pure Python and defines no FFI; its
+ * boundary for this path is the Python call contract of splib/spcpl.py.  Each entry point below
+ * replaces the *arithmetic* of one group of reference functions for ALL SP columns at once; the
+ * Python host mirror (sp_coupler_amd/spcpl.py) keeps the reference's function names on top of it.
+ *
+ *   spc_forward_*        <- spcpl.convert_profiles        splib/spcpl.py:171-246
+ *                           spcpl.set_les_forcings        splib/spcpl.py:299-385 (arithmetic 316-333)
+ *                           spcpl.convert_surface_fluxes  splib/spcpl.py:136-167 (optional)
+ *                           index map of get_les_profiles splib/spcpl.py:761-764 (optional, fused)
+ *                           sputils.interp / iexner       splib/sputils.py:82-86, 33-34
+ *   spc_cloud_indices_*  <- spcpl.get_cloud_fraction      splib/spcpl.py:22-29 (line 26)
+ *                           spcpl.get_les_profiles        splib/spcpl.py:761-764
+ *                           sputils.searchsorted          splib/sputils.py:88-91
+ *   spc_backward_*       <- spcpl.set_gcm_tendencies      splib/spcpl.py:388-555 (arithmetic 402-533)
+ *                           sputils.interp_c / integral   splib/sputils.py:94-189 (conservative=1)
+ *   spc_diagnostics_*    <- spifs.nc diagnostics          splib/spcpl.py:176,214-215,408-409;
+ *                           spcpl.output_column_conversion splib/spcpl.py:251-267
+ *
+ * Conventions
+ *   - All data pointers are DEVICE pointers (HBM) owned by the caller; the library never allocates,
+ *     frees or copies them and keeps no global state except the last-error string (thread local).
+ *   - Element type is double for *_f64 and float for *_f32; index outputs are int32_t.
+ *   - Arrays are row-major [n_cols x n_lev] with an explicit element pitch between columns.
+ *       GCM full-level arrays   [n_cols x nG]     pitchG  (index 0 = model top, nG-1 = lowest level)
+ *       GCM half-level arrays   [n_cols x (nG+1)] pitchGh (index nG = surface)
+ *       LES arrays              [n_cols x nL]     pitchL  (index 0 = lowest level, ascending)
+ *       per-column scalars      [n_cols]
+ *     The LES grids zf / zh are [nL] shared by all columns when les_grid_shared != 0, else
+ *     [n_cols x nL] with pitchL.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls only enqueue work.
+ *   - Optional pointers may be NULL; the corresponding work/outputs are skipped.
+ *   - Every function returns 0 on success or a negative spc_status; spc_last_error() gives the text.
+ *     No C++ exception crosses the ABI.
+ */
+#ifndef SPC_H
+#define SPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPC_ABI_VERSION 1
+
+typedef enum spc_status {
+    SPC_OK = 0,
+    SPC_ERR_INVALID_ARGUMENT = -1, /* NULL required pointer, bad dims or pitches              */
+    SPC_ERR_UNSUPPORTED = -2,      /* level counts exceed what the kernels' LDS staging holds */
+    SPC_ERR_LAUNCH = -3,           /* hipLaunchKernel / runtime error (see spc_last_error)    */
+    SPC_ERR_NO_DEVICE = -4         /* no HIP device available                                 */
+} spc_status;
+
+typedef struct spc_dims {
+    int64_t n_cols;          /* number of SP columns in the batch (0 is allowed: no-op)          */
+    int32_t nG;              /* GCM full levels (19 / 91 / 137 ...)                              */
+    int32_t nL;              /* LES levels (160 / 512 ...)                                       */
+    int64_t pitchG;          /* elements between columns of [n_cols x nG] arrays,   >= nG        */
+    int64_t pitchGh;         /* elements between columns of [n_cols x nG+1] arrays, >= nG+1      */
+    int64_t pitchL;          /* elements between columns of [n_cols x nL] arrays,   >= nL        */
+    int32_t les_grid_shared; /* 1: zf/zh are [nL]; 0: zf/zh are [n_cols x nL]                    */
+    int32_t cols_per_block;  /* tuning: columns per 256-thread workgroup (0 = library heuristic) */
+} spc_dims;
+
+/* ---- forward: GCM state -> LES profiles + nudging forcings (kernel K1, K2 fused) ------------- */
+typedef struct spc_forward_args {
+    /* GCM inputs, spcpl.gather_gcm_data var list (spcpl.py:32). `A` is not used by this pass. */
+    const void *U, *V, *T, *SH, *QL, *QI, *Pf; /* [n_cols x nG]                                  */
+    const void *Ph;                            /* [n_cols x nG+1]; only Ph[nG] (surface) is read */
+    const void *Zgfull;                        /* [n_cols x nG]   geopotential, full levels      */
+    const void *Zghalf;                        /* [n_cols x nG+1] geopotential, half levels      */
+    /* LES grid and slab means (profile[...] of spcpl.py:310-315)                               */
+    const void *zf;                            /* LES full-level heights (les.zf_cache)          */
+    const void *zh;                            /* LES half-level heights; only needed for `idx`  */
+    const void *u_d, *v_d, *thl_d, *qt_d, *ql_d; /* [n_cols x nL]                                */
+    const void *ps_d;                          /* [n_cols]                                       */
+    const void *rain, *rain_last;              /* [n_cols], optional (both or neither)           */
+    double factor;                             /* les_forcing_factor                             */
+    double dt;                                 /* dt_gcm in seconds                              */
+    /* required outputs (what the 7 setters of spcpl.py:341-347 receive)                        */
+    void *f_u, *f_v, *f_thl, *f_qt, *f_ql, *ql_ref; /* [n_cols x nL]                            */
+    void *f_ps;                                /* [n_cols]                                       */
+    /* optional outputs                                                                         */
+    void *u, *v, *thl, *qt;                    /* [n_cols x nL] interpolated profiles (return value
+                                                  of convert_profiles; ql == ql_ref)            */
+    void *ps;                                  /* [n_cols] Ph[nG]                                */
+    void *Zf;                                  /* [n_cols x nG]   les.gcm_Zf (spcpl.py:200)      */
+    void *Zh;                                  /* [n_cols x nG+1] les.gcm_Zh (spcpl.py:201)      */
+    void *rainrate;                            /* [n_cols] (rain-rain_last)/dt (spcpl.py:325)    */
+    int32_t *idx;                              /* [n_cols x nG] pitchG: cloud-fraction level map,
+                                                  searchsorted(zh,Zh,'right')[:-1][::-1]         */
+    /* optional surface coupling (cplsurf): inputs [n_cols], outputs [n_cols]                   */
+    const void *Z0M, *Z0H, *QLflux, *QIflux, *SHflux, *TSflux;
+    void *z0m, *z0h, *wthl, *wqt;
+} spc_forward_args;
+
+int spc_forward_f64(const spc_dims *dims, const spc_forward_args *args, void *stream);
+int spc_forward_f32(const spc_dims *dims, const spc_forward_args *args, void *stream);
+
+/* ---- index map only (kernel K2 standalone) --------------------------------------------------- */
+/* Zh: [n_cols x nG+1] heights of GCM half levels (descending, Zh[nG] = 0), as cached by forward.
+ * idx[c][m] = searchsorted(zh, Zh[c], side='right')[nG-1-m], m = 0..nG-1; values in 0..nL.       */
+int spc_cloud_indices_f64(const spc_dims *dims, const void *zh, const void *Zh, int32_t *idx, void *stream);
+int spc_cloud_indices_f32(const spc_dims *dims, const void *zh, const void *Zh, int32_t *idx, void *stream);
+
+/* ---- backward: LES slab means -> GCM tendencies (kernel K3; K4 when conservative) ------------ */
+typedef struct spc_backward_args {
+    const void *T, *SH, *QL, *QI, *U, *V, *A; /* [n_cols x nG] GCM state                        */
+    const void *Zf;                           /* [n_cols x nG] les.gcm_Zf; may be NULL when
+                                                 Zgfull and Zghalf are given (recomputed)       */
+    const void *Zgfull, *Zghalf;              /* optional, see Zf                               */
+    const void *zf;                           /* LES full-level heights                         */
+    const void *t_d, *qt_d, *ql_d, *ql_ice_d, *u_d, *v_d; /* [n_cols x nL] profile[T,QT,QL,QL_ice,U,V] */
+    const void *A_prof;                       /* [n_cols x nG] pitchG: profile["A"] in the order
+                                                 get_cloudfraction(indices) returns it (ascending
+                                                 height); reversed in-kernel (spcpl.py:404)     */
+    /* conservative coarsening (sputils.interp_c); required only when conservative != 0        */
+    const void *zh;                           /* LES half-level heights                         */
+    const void *Zh;                           /* [n_cols x nG+1] or NULL with Zghalf given      */
+    const void *rhobf_d;                      /* [n_cols x nL] profile["Rhobf"]                 */
+    int32_t conservative;
+    int32_t reserved;
+    double factor;                            /* gcm_forcing_factor                             */
+    double dt;                                /* dt_gcm in seconds                              */
+    void *f_T, *f_SH, *f_QL, *f_QI, *f_U, *f_V, *f_A; /* [n_cols x nG] outputs                  */
+    int32_t *start_index;                     /* [n_cols] optional                              */
+} spc_backward_args;
+
+int spc_backward_f64(const spc_dims *dims, const spc_backward_args *args, void *stream);
+int spc_backward_f32(const spc_dims *dims, const spc_backward_args *args, void *stream);
+
+/* ---- diagnostics for spifs.nc (kernel K5) ----------------------------------------------------- */
+typedef struct spc_diagnostics_args {
+    const void *T, *SH, *QL, *QI, *Pf;        /* [n_cols x nG]                                  */
+    const void *Zgfull, *Zghalf;              /* geopotential                                   */
+    const void *zf;                           /* LES heights; with thl_d, ql_d for `t`          */
+    const void *thl_d, *ql_d, *ql_ice_d;      /* [n_cols x nL] optional                         */
+    void *Tv, *THL, *QT;                      /* [n_cols x nG] optional outputs (spcpl.py:176,214,215) */
+    void *Zf;                                 /* [n_cols x nG]   optional                       */
+    void *Zh;                                 /* [n_cols x nG+1] optional                       */
+    void *pf, *t, *ql_water;                  /* [n_cols x nL] optional (spcpl.py:408,409,402)  */
+} spc_diagnostics_args;
+
+int spc_diagnostics_f64(const spc_dims *dims, const spc_diagnostics_args *args, void *stream);
+int spc_diagnostics_f32(const spc_dims *dims, const spc_diagnostics_args *args, void *stream);
+
+/* ---- misc ----------------------------------------------------------------------------------- */
+int spc_abi_version(void);          /* == SPC_ABI_VERSION                                          */
+const char *spc_last_error(void);   /* text of the calling thread's last failure ("" if none)     */
+int spc_device_count(void);         /* number of visible HIP devices (0 if none / no driver)      */
+/* columns per workgroup the library would pick for these dims (pass = 0 forward, 1 backward)     */
+int spc_pick_cols_per_block(const spc_dims *dims, int pass);
+/* Measured device-to-device copy rate helper for roofline reporting: copies `bytes` from src to
+ * dst with a 16 B/lane streaming kernel on `stream`.                                              */
+int spc_stream_copy(void *dst, const void *src, int64_t bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPC_H */

@@ -1,0 +1,320 @@
+"""Host launcher for the HIP coupling kernels: torch tensors in HBM -> C ABI (include/spc.h).
+
+PyTorch is plumbing here (device memory, streams); every number is produced by the hand-written
+kernels in csrc/spc_hip.hip.  There is no CPU fallback: constructing an ``Engine`` without the built
+extension or without a GPU raises.
+
+A *plan* (``ForwardPlan`` / ``BackwardPlan``) validates shapes once, freezes the ctypes argument block
+and can then be launched repeatedly with one foreign call -- what the per-step driver and ``bench.py``
+use, so host overhead per step stays at two launches.
+"""
+import ctypes
+
+import torch
+
+from . import _abi
+
+GCM_FULL = ("U", "V", "T", "SH", "QL", "QI", "Pfull", "A", "Zgfull")   # [n x nG]   (spcpl.py:32)
+GCM_HALF = ("Phalf", "Zghalf")                                        # [n x nG+1]
+SURF_IN = ("Z0M", "Z0H", "QLflux", "QIflux", "SHflux", "TSflux")      # [n]        (spcpl.py:33,138)
+FWD_LES = ("U", "V", "THL", "QT", "QL")                               # profile[...] spcpl.py:310-314
+BWD_LES = ("T", "QT", "QL", "QL_ice", "U", "V")                       # profile[...] spcpl.py:393-411
+
+_DTYPES = {torch.float64: "f64", torch.float32: "f32"}
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    return ctypes.c_void_p(stream.cuda_stream)
+
+
+class _Checker:
+    """Shape / layout validation done on the host BEFORE any launch (a kernel never sees a tensor
+    whose extent differs from what its grid assumes)."""
+
+    def __init__(self, device, dtype):
+        self.device, self.dtype = device, dtype
+        self.keep = []
+
+    def mat(self, name, t, n, m, pitch=None):
+        if not isinstance(t, torch.Tensor):
+            raise TypeError("%s must be a torch.Tensor, got %s" % (name, type(t).__name__))
+        if t.device != self.device:
+            raise ValueError("%s is on %s, engine is on %s" % (name, t.device, self.device))
+        if t.dtype != self.dtype:
+            raise ValueError("%s has dtype %s, engine computes in %s" % (name, t.dtype, self.dtype))
+        if t.dim() != 2 or t.shape[0] != n or t.shape[1] != m:
+            raise ValueError("%s must have shape [%d x %d], got %s" % (name, n, m, tuple(t.shape)))
+        if m > 1 and t.stride(1) != 1:
+            raise ValueError("%s must be contiguous along levels (stride %s)" % (name, t.stride()))
+        p = t.stride(0) if n > 1 else (pitch if pitch is not None else max(m, t.stride(0)))
+        if pitch is not None and n > 1 and p != pitch:
+            raise ValueError("%s has column pitch %d, batch uses %d" % (name, p, pitch))
+        if p < m:
+            raise ValueError("%s has column pitch %d < %d levels" % (name, p, m))
+        self.keep.append(t)
+        return t.data_ptr(), p
+
+    def vec(self, name, t, n, dtype=None):
+        if not isinstance(t, torch.Tensor):
+            raise TypeError("%s must be a torch.Tensor, got %s" % (name, type(t).__name__))
+        if t.device != self.device or t.dtype != (dtype or self.dtype):
+            raise ValueError("%s must be %s on %s" % (name, dtype or self.dtype, self.device))
+        if t.dim() != 1 or t.shape[0] != n or (n > 1 and t.stride(0) != 1):
+            raise ValueError("%s must be a contiguous vector of %d, got %s" % (name, n, tuple(t.shape)))
+        self.keep.append(t)
+        return t.data_ptr()
+
+
+class _Plan:
+    def __init__(self, engine, fn, dims, args, keep, outputs):
+        self.engine, self._fn, self.dims, self.args, self._keep, self.outputs = engine, fn, dims, args, keep, outputs
+        self._dref, self._aref = ctypes.byref(dims), ctypes.byref(args)
+
+    def launch(self, stream=None):
+        """Enqueue the kernel on ``stream`` (default: torch's current stream). Returns outputs dict."""
+        rc = self._fn(self._dref, self._aref, _stream_ptr(stream))
+        if rc:
+            _abi.check(self.engine.lib, rc)
+        return self.outputs
+
+    def launch_raw(self, stream_ptr):
+        """Same with a pre-fetched ``ctypes.c_void_p`` stream handle (hot loops)."""
+        rc = self._fn(self._dref, self._aref, stream_ptr)
+        if rc:
+            _abi.check(self.engine.lib, rc)
+
+
+class ForwardPlan(_Plan):
+    pass
+
+
+class BackwardPlan(_Plan):
+    pass
+
+
+class Engine:
+    """One engine per (device, dtype). ``dtype`` is the arithmetic type of the path: float64 as in
+    the reference (AMUSE quantities wrap float64 arrays), float32 for the tolerance sweep."""
+
+    def __init__(self, device=None, dtype=torch.float64):
+        self.lib = _abi.load_library()          # raises SpcLibraryError if the HIP extension is missing
+        if dtype not in _DTYPES:
+            raise ValueError("dtype must be torch.float64 or torch.float32")
+        if not torch.cuda.is_available() or self.lib.spc_device_count() < 1:
+            raise RuntimeError("sp_coupler_amd.Engine needs a HIP device (MI355X); there is no CPU fallback")
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        if self.device.type != "cuda":
+            raise ValueError("Engine device must be a cuda/HIP device")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.dtype = dtype
+        sfx = _DTYPES[dtype]
+        self._fwd = getattr(self.lib, "spc_forward_" + sfx)
+        self._bwd = getattr(self.lib, "spc_backward_" + sfx)
+        self._idx = getattr(self.lib, "spc_cloud_indices_" + sfx)
+        self._diag = getattr(self.lib, "spc_diagnostics_" + sfx)
+
+    # -- helpers ----------------------------------------------------------------------------
+    def _grid(self, ck, name, z, n, nL, pitchL):
+        """LES grid: [nL] shared by all columns or [n x nL]."""
+        if z.dim() == 1:
+            return ck.vec(name, z, nL), 1
+        ptr, _ = ck.mat(name, z, n, nL, pitchL)
+        return ptr, 0
+
+    def empty(self, *shape, dtype=None):
+        return torch.empty(*shape, device=self.device, dtype=dtype or self.dtype)
+
+    # -- K1 (+K2) ---------------------------------------------------------------------------
+    def plan_forward(self, gcm, zf, prof, factor, dt, zh=None, *, want_profiles=False, want_heights=True,
+                     want_idx=None, couple_surface=False, cols_per_block=0, out=None):
+        """Arithmetic of convert_profiles + set_les_forcings (splib/spcpl.py:171-246, 299-385) for all
+        columns. ``gcm``: dict of the gcm_vars tensors; ``prof``: dict U,V,THL,QT,QL [n x nL], PS [n]
+        (+ Rain, rain_last [n]). Output tensors are allocated here (or taken from ``out``)."""
+        T_ = gcm["T"]
+        n, nG = int(T_.shape[0]), int(T_.shape[1])
+        nL = int(prof["U"].shape[1])
+        ck = _Checker(self.device, self.dtype)
+        a = _abi.ForwardArgs()
+        pitchG = pitchGh = pitchL = None
+        for key, field in (("U", "U"), ("V", "V"), ("T", "T"), ("SH", "SH"), ("QL", "QL"), ("QI", "QI"),
+                           ("Pfull", "Pf"), ("Zgfull", "Zgfull")):
+            ptr, pitchG = ck.mat("gcm[%s]" % key, gcm[key], n, nG, pitchG)
+            setattr(a, field, ptr)
+        for key, field in (("Phalf", "Ph"), ("Zghalf", "Zghalf")):
+            ptr, pitchGh = ck.mat("gcm[%s]" % key, gcm[key], n, nG + 1, pitchGh)
+            setattr(a, field, ptr)
+        for key, field in zip(FWD_LES, ("u_d", "v_d", "thl_d", "qt_d", "ql_d")):
+            ptr, pitchL = ck.mat("prof[%s]" % key, prof[key], n, nL, pitchL)
+            setattr(a, field, ptr)
+        a.ps_d = ck.vec("prof[PS]", prof["PS"], n)
+        a.zf, shared = self._grid(ck, "zf", zf, n, nL, pitchL)
+        if want_idx is None:
+            want_idx = zh is not None
+        out = dict(out or {})
+        res = {}
+
+        def omat(name, m, pitch):
+            t = out.get(name)
+            if t is None:
+                t = torch.empty(n, pitch or m, device=self.device, dtype=self.dtype)[:, :m]
+            ptr, _ = ck.mat("out[%s]" % name, t, n, m, pitch)
+            res[name] = t
+            return ptr
+
+        def ovec(name):
+            t = out.get(name)
+            if t is None:
+                t = self.empty(n)
+            res[name] = t
+            return ck.vec("out[%s]" % name, t, n)
+
+        for name in ("f_u", "f_v", "f_thl", "f_qt", "f_ql", "ql_ref"):
+            setattr(a, name, omat(name, nL, pitchL))
+        a.f_ps = ovec("f_ps")
+        if want_profiles:
+            for name in ("u", "v", "thl", "qt"):
+                setattr(a, name, omat(name, nL, pitchL))
+            a.ps = ovec("ps")
+        if want_heights:
+            a.Zf = omat("Zf", nG, pitchG)
+            a.Zh = omat("Zh", nG + 1, pitchGh)
+        if want_idx:
+            if zh is None:
+                raise ValueError("want_idx needs the LES half-level heights zh")
+            a.zh, sh2 = self._grid(ck, "zh", zh, n, nL, pitchL)
+            if sh2 != shared:
+                raise ValueError("zf and zh must both be shared [nL] or both per column [n x nL]")
+            idx = out.get("idx")
+            if idx is None:  # idx shares the column pitch of the GCM full-level arrays
+                idx = torch.empty(n, pitchG or nG, device=self.device, dtype=torch.int32)[:, :nG]
+            if (idx.dtype != torch.int32 or idx.device != self.device or tuple(idx.shape) != (n, nG)
+                    or (nG > 1 and idx.stride(1) != 1) or (n > 1 and idx.stride(0) != pitchG)):
+                raise ValueError("out[idx] must be int32 [%d x %d] with column pitch %d" % (n, nG, pitchG))
+            ck.keep.append(idx)
+            a.idx = idx.data_ptr()
+            res["idx"] = idx
+        if "Rain" in prof and "rain_last" in prof:
+            a.rain = ck.vec("prof[Rain]", prof["Rain"], n)
+            a.rain_last = ck.vec("prof[rain_last]", prof["rain_last"], n)
+            a.rainrate = ovec("rainrate")
+        if couple_surface:
+            for key in SURF_IN:
+                setattr(a, key, ck.vec("gcm[%s]" % key, gcm[key], n))
+            for name in ("z0m", "z0h", "wthl", "wqt"):
+                setattr(a, name, ovec(name))
+        a.factor, a.dt = float(factor), float(dt)
+        dims = _abi.Dims(n, nG, nL, pitchG or nG, pitchGh or nG + 1, pitchL or nL, shared, int(cols_per_block))
+        return ForwardPlan(self, self._fwd, dims, a, ck.keep, res)
+
+    def forward(self, *args, stream=None, **kw):
+        return self.plan_forward(*args, **kw).launch(stream)
+
+    # -- K2 standalone ----------------------------------------------------------------------
+    def cloud_indices(self, zh, Zh, stream=None, cols_per_block=0):
+        """searchsorted(zh, Zh, 'right')[:-1][::-1] per column (splib/spcpl.py:26, 764)."""
+        n, nGp1 = int(Zh.shape[0]), int(Zh.shape[1])
+        nG = nGp1 - 1
+        nL = int(zh.shape[-1])
+        ck = _Checker(self.device, self.dtype)
+        Zh_ptr, pitchGh = ck.mat("Zh", Zh, n, nG + 1)
+        zh_ptr, shared = self._grid(ck, "zh", zh, n, nL, None)
+        pitchL = zh.stride(0) if (zh.dim() == 2 and n > 1) else nL
+        idx = self.empty(n, nG, dtype=torch.int32)
+        dims = _abi.Dims(n, nG, nL, nG, pitchGh, pitchL, shared, int(cols_per_block))
+        rc = self._idx(ctypes.byref(dims), zh_ptr, Zh_ptr, idx.data_ptr(), _stream_ptr(stream))
+        _abi.check(self.lib, rc)
+        return idx
+
+    # -- K3 ---------------------------------------------------------------------------------
+    def plan_backward(self, gcm, zf, prof, factor, dt, Zf=None, *, want_start_index=True, conservative=False,
+                      cols_per_block=0, out=None):
+        """Arithmetic of set_gcm_tendencies (splib/spcpl.py:388-555) for all columns. ``prof``: dict
+        T,QT,QL,QL_ice,U,V [n x nL] and A [n x nG] (order of get_cloudfraction(indices))."""
+        T_ = gcm["T"]
+        n, nG = int(T_.shape[0]), int(T_.shape[1])
+        nL = int(prof["T"].shape[1])
+        ck = _Checker(self.device, self.dtype)
+        a = _abi.BackwardArgs()
+        pitchG = pitchGh = pitchL = None
+        for key in ("T", "SH", "QL", "QI", "U", "V", "A"):
+            ptr, pitchG = ck.mat("gcm[%s]" % key, gcm[key], n, nG, pitchG)
+            setattr(a, key, ptr)
+        if Zf is not None:
+            a.Zf, pitchG = ck.mat("Zf", Zf, n, nG, pitchG)
+        else:
+            a.Zgfull, pitchG = ck.mat("gcm[Zgfull]", gcm["Zgfull"], n, nG, pitchG)
+            a.Zghalf, pitchGh = ck.mat("gcm[Zghalf]", gcm["Zghalf"], n, nG + 1, pitchGh)
+        for key, field in zip(BWD_LES, ("t_d", "qt_d", "ql_d", "ql_ice_d", "u_d", "v_d")):
+            ptr, pitchL = ck.mat("prof[%s]" % key, prof[key], n, nL, pitchL)
+            setattr(a, field, ptr)
+        a.A_prof, pitchG = ck.mat("prof[A]", prof["A"], n, nG, pitchG)
+        a.zf, shared = self._grid(ck, "zf", zf, n, nL, pitchL)
+        a.conservative = 1 if conservative else 0
+        a.factor, a.dt = float(factor), float(dt)
+        out = dict(out or {})
+        res = {}
+        for name in ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A"):
+            t = out.get(name)
+            if t is None:
+                t = self.empty(n, nG)
+            ptr, pitchG = ck.mat("out[%s]" % name, t, n, nG, pitchG)
+            setattr(a, name, ptr)
+            res[name] = t
+        if want_start_index:
+            t = out.get("start_index")
+            if t is None:
+                t = self.empty(n, dtype=torch.int32)
+            a.start_index = ck.vec("out[start_index]", t, n, dtype=torch.int32)
+            res["start_index"] = t
+        dims = _abi.Dims(n, nG, nL, pitchG or nG, pitchGh or nG + 1, pitchL or nL, shared, int(cols_per_block))
+        return BackwardPlan(self, self._bwd, dims, a, ck.keep, res)
+
+    def backward(self, *args, stream=None, **kw):
+        return self.plan_backward(*args, **kw).launch(stream)
+
+    # -- K5 ---------------------------------------------------------------------------------
+    def diagnostics(self, gcm, zf=None, prof=None, stream=None, cols_per_block=0):
+        """spifs.nc diagnostics: Tv, THL, QT, Zf, Zh (splib/spcpl.py:176,197-198,214-215) and, when
+        ``zf``/``prof`` are given, pf, t, ql_water on LES levels (splib/spcpl.py:402,408-409)."""
+        T_ = gcm["T"]
+        n, nG = int(T_.shape[0]), int(T_.shape[1])
+        ck = _Checker(self.device, self.dtype)
+        a = _abi.DiagnosticsArgs()
+        pitchG = pitchGh = pitchL = None
+        for key, field in (("T", "T"), ("SH", "SH"), ("QL", "QL"), ("QI", "QI"), ("Pfull", "Pf"), ("Zgfull", "Zgfull")):
+            ptr, pitchG = ck.mat("gcm[%s]" % key, gcm[key], n, nG, pitchG)
+            setattr(a, field, ptr)
+        a.Zghalf, pitchGh = ck.mat("gcm[Zghalf]", gcm["Zghalf"], n, nG + 1, pitchGh)
+        res = {}
+        for name in ("Tv", "THL", "QT", "Zf"):
+            res[name] = self.empty(n, nG)
+            ptr, pitchG = ck.mat(name, res[name], n, nG, pitchG)
+            setattr(a, name, ptr)
+        res["Zh"] = self.empty(n, nG + 1)
+        a.Zh, pitchGh = ck.mat("Zh", res["Zh"], n, nG + 1, pitchGh)
+        nL, shared = 1, 1
+        if zf is not None and prof is not None:
+            nL = int(prof["THL"].shape[1])
+            for key, field in (("THL", "thl_d"), ("QL", "ql_d"), ("QL_ice", "ql_ice_d")):
+                ptr, pitchL = ck.mat("prof[%s]" % key, prof[key], n, nL, pitchL)
+                setattr(a, field, ptr)
+            a.zf, shared = self._grid(ck, "zf", zf, n, nL, pitchL)
+            for name in ("pf", "t", "ql_water"):
+                res[name] = self.empty(n, nL)
+                ptr, pitchL = ck.mat(name, res[name], n, nL, pitchL)
+                setattr(a, name, ptr)
+        dims = _abi.Dims(n, nG, nL, pitchG or nG, pitchGh or nG + 1, pitchL or nL, shared, int(cols_per_block))
+        rc = self._diag(ctypes.byref(dims), ctypes.byref(a), _stream_ptr(stream))
+        _abi.check(self.lib, rc)
+        return res
+
+    # -- measured copy bandwidth yardstick ----------------------------------------------------
+    def stream_copy(self, dst, src, stream=None):
+        nbytes = src.numel() * src.element_size()
+        if dst.numel() * dst.element_size() != nbytes or not (src.is_contiguous() and dst.is_contiguous()):
+            raise ValueError("stream_copy needs two contiguous tensors of equal byte size")
+        rc = self.lib.spc_stream_copy(dst.data_ptr(), src.data_ptr(), nbytes, _stream_ptr(stream))
+        _abi.check(self.lib, rc)

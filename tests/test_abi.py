@@ -1,0 +1,103 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/spc.h declares (no compute call is made without a GPU), and the ctypes mirror matches it."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+import __graft_entry__ as ge
+from sp_coupler_amd import _abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    ge.build_hip()
+    return _abi.load_library()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "spc.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(spc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported_and_bound(lib):
+    declared = _declared_symbols()
+    assert len(declared) >= 13
+    assert sorted(_abi.PROTOTYPES) == declared          # python mirror covers exactly the header
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_abi_version_and_error_text(lib):
+    assert lib.spc_abi_version() == _abi.ABI_VERSION == 1
+    assert isinstance(lib.spc_last_error(), bytes)
+
+
+def test_struct_layout_matches_c_compiler(tmp_path):
+    """sizeof/offsetof as gcc sees include/spc.h == the ctypes mirror."""
+    probes = [("spc_dims", _abi.Dims, ["n_cols", "nG", "nL", "pitchG", "pitchGh", "pitchL", "les_grid_shared", "cols_per_block"]),
+              ("spc_forward_args", _abi.ForwardArgs, ["U", "zf", "rain_last", "factor", "dt", "f_u", "idx", "Z0M", "wqt"]),
+              ("spc_backward_args", _abi.BackwardArgs, ["T", "A_prof", "rhobf_d", "conservative", "factor", "dt", "f_T", "start_index"]),
+              ("spc_diagnostics_args", _abi.DiagnosticsArgs, ["T", "zf", "Tv", "ql_water"])]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "spc.h"', 'int main(void){']
+    for cname, _, fields in probes:
+        lines.append('printf("%%zu\\n", sizeof(%s));' % cname)
+        for f in fields:
+            lines.append('printf("%%zu\\n", offsetof(%s, %s));' % (cname, f))
+    lines.append('return 0;}')
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    want = []
+    for _, cls, fields in probes:
+        want.append(ctypes.sizeof(cls))
+        want += [getattr(cls, f).offset for f in fields]
+    assert got == want
+
+
+def test_invalid_arguments_are_rejected_without_a_gpu(lib):
+    """Argument validation happens on the host before any launch: error codes and texts, no crash."""
+    d = _abi.Dims(4, 91, 160, 91, 92, 160, 1, 0)
+    a = _abi.ForwardArgs()                                   # all pointers NULL
+    assert lib.spc_forward_f64(ctypes.byref(d), ctypes.byref(a), None) == _abi.SPC_ERR_INVALID_ARGUMENT
+    assert b"NULL" in lib.spc_last_error()
+    bad = _abi.Dims(4, 91, 160, 90, 92, 160, 1, 0)           # pitch < levels
+    assert lib.spc_forward_f64(ctypes.byref(bad), ctypes.byref(a), None) == _abi.SPC_ERR_INVALID_ARGUMENT
+    assert b"pitch" in lib.spc_last_error()
+    neg = _abi.Dims(-1, 91, 160, 91, 92, 160, 1, 0)
+    assert lib.spc_backward_f64(ctypes.byref(neg), ctypes.byref(_abi.BackwardArgs()), None) == _abi.SPC_ERR_INVALID_ARGUMENT
+    with pytest.raises(_abi.SpcInvalidArgument):
+        _abi.check(lib, lib.spc_cloud_indices_f64(ctypes.byref(d), None, None, None, None))
+    empty = _abi.Dims(0, 91, 160, 91, 92, 160, 1, 0)          # empty batch is a no-op, not an error
+    assert lib.spc_forward_f64(ctypes.byref(empty), ctypes.byref(a), None) == 0
+    assert lib.spc_backward_f64(ctypes.byref(empty), ctypes.byref(_abi.BackwardArgs()), None) == 0
+
+
+def test_cols_per_block_heuristic(lib):
+    small = _abi.Dims(1024, 91, 160, 91, 92, 160, 1, 0)
+    big = _abi.Dims(348528, 91, 160, 91, 92, 160, 1, 0)
+    assert lib.spc_pick_cols_per_block(ctypes.byref(small), 0) == 1
+    assert lib.spc_pick_cols_per_block(ctypes.byref(big), 0) == 8
+    tall = _abi.Dims(348528, 137, 512, 137, 138, 512, 1, 0)   # backward LDS: 6*512+137 doubles per column
+    assert 1 <= lib.spc_pick_cols_per_block(ctypes.byref(tall), 1) <= 2
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(_abi.SpcLibraryError):
+        _abi.load_library(str(tmp_path / "libspc_hip.so"))
+
+
+def test_engine_refuses_to_run_without_gpu(lib):
+    import torch
+    from sp_coupler_amd.engine import Engine
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Engine()

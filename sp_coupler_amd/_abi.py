@@ -99,7 +99,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("SPC_LIB") or LIB_PATH   # SPC_LIB: A/B a variant build of the same ABI
     if not os.path.exists(p):
         raise SpcLibraryError(
             "HIP extension %s not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -24,7 +24,8 @@ def assert_bits(name, got, want):
     same = (got == want) | (numpy.isnan(got) & numpy.isnan(want))
     assert same.all(), "%s: %d of %d elements differ (max abs %.3e)" % (
         name, (~same).sum(), same.size, numpy.nanmax(numpy.abs(got - want)))
-    assert numpy.array_equal(numpy.signbit(got), numpy.signbit(want)), name + ": sign of zero differs"
+    num = ~numpy.isnan(want)   # the sign bit of a NaN carries no meaning (differs between x86 and gfx950)
+    assert numpy.array_equal(numpy.signbit(got)[num], numpy.signbit(want)[num]), name + ": sign of zero differs"
 
 
 def assert_close_scaled(name, got, want, tol, scale):

@@ -105,12 +105,25 @@ def test_edge_columns(eng):
     # col 0: no condensate at all
     gcm["QL"][0] = 0.0
     gcm["QI"][0] = 0.0
-    # col 1: some GCM full levels sit EXACTLY on LES full levels, some half levels exactly on LES half levels
+    # col 1: a monotone column in which many GCM full levels sit EXACTLY on LES full levels and several
+    # half levels exactly on LES half levels (x == xp[j] branch of numpy.interp, side='right' ties)
     gcm["Zghalf"][1, -1] = 0.0
-    for k, lev in ((90, 3), (88, 40), (85, 159)):
-        gcm["Zgfull"][1, k] = _ulp_search(zf[lev], grav)
-    for k, lev in ((90, 2), (87, 41)):
-        gcm["Zghalf"][1, k] = _ulp_search(zh[lev], grav)
+    low = []
+    for lev in range(150, -1, -10):
+        low += [zf[lev], zf[lev] - 3.3]
+    Zf1 = numpy.concatenate([numpy.linspace(60000.0, 4100.0, 58), [zf[159]], low])
+    assert Zf1.shape == (91,) and (numpy.diff(Zf1) < 0).all()
+    exact_full = [k for k in range(91) if Zf1[k] in zf]
+    gcm["Zgfull"][1] = [_ulp_search(t, grav) if k in exact_full else t * grav for k, t in enumerate(Zf1)]
+    Zh1 = numpy.concatenate([[61000.0], 0.5 * (Zf1[:-1] + Zf1[1:]), [0.0]])
+    exact_half = []
+    for k in range(1, 91):
+        m = numpy.ceil(Zf1[k] / 25.0) * 25.0
+        if Zf1[k] < m < Zf1[k - 1] and m <= zh[-1] and k % 3 == 0:
+            Zh1[k] = m
+            exact_half.append(k)
+    gcm["Zghalf"][1] = [_ulp_search(t, grav) if k in exact_half else t * grav for k, t in enumerate(Zh1)]
+    assert len(exact_full) >= 17 and len(exact_half) >= 3
     # col 2: whole GCM column squeezed below the lowest LES level (every LES level clamps to the top value)
     gcm["Zgfull"][2] = gcm["Zghalf"][2, -1] + numpy.linspace(10.0, 0.5, 91) * grav
     gcm["Zghalf"][2, :-1] = gcm["Zghalf"][2, -1] + numpy.linspace(10.5, 0.7, 91) * grav
@@ -131,7 +144,8 @@ def test_edge_columns(eng):
         ref_f = orc.forward_batched(gcm, prof, zf, zh, FACTOR, DT, couple_surface=True)
         ref_b = orc.backward_batched(gcm, ref_f["Zf"], prof, zf, FACTOR, DT)
     # the fixture really exercises what it claims
-    assert (ref_f["Zf"][1, 90] == zf[3]) and (ref_f["Zf"][1, 85] == zf[159]) and (ref_f["Zh"][1, 87] == zh[41])
+    assert all(ref_f["Zf"][1, k] == Zf1[k] for k in exact_full) and all(ref_f["Zh"][1, k] == Zh1[k] for k in exact_half)
+    assert (numpy.diff(ref_f["Zf"], axis=1) < 0).all()       # numpy.interp needs monotone abscissae
     assert ref_b["start_index"][2] == 0 and ref_b["start_index"][3] == 91
     assert numpy.isnan(ref_b["f_T"][4, 0]) and numpy.signbit(ref_b["f_U"][4]).any()
     fwd, bwd = run_gpu(eng, gcm, zf, zh, prof)

@@ -21,6 +21,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <type_traits>
+#include <unordered_map>
+
 #include "spc.h"
 
 #pragma clang fp contract(off)
@@ -46,6 +49,14 @@ template <typename T> struct K {
 
 __device__ __forceinline__ double spc_pow(double x, double y) { return pow(x, y); }
 __device__ __forceinline__ float spc_pow(float x, float y) { return powf(x, y); }
+
+// Every quotient on this path is a true IEEE division (x / y), never x * (1/y): the reference divides,
+// and bit-parity of the u/v/qt/ql forcings and of all tendencies depends on it.  (Tried and measured
+// slower on gfx950: RN(1/y) shared by the 5-7 slopes of a level + two FMA Newton steps + v_div_fixup;
+// the magnitude-window checks it needs cost more than hipcc's v_div_scale/v_rcp/v_div_fmas expansion.)
+template <typename T> __device__ __forceinline__ T div_grav(T x) { return x / K<T>::grav; }
+template <typename T> __device__ __forceinline__ T div_cp(T x) { return x / K<T>::cp; }
+template <typename T> __device__ __forceinline__ T div_pref0(T x) { return x / K<T>::pref0; }
 
 // numpy NaN-aware "a < b" used by searchsorted (NaN sorts to the end)
 template <typename T> __device__ __forceinline__ bool np_lt(T a, T b) { return a < b || (b != b && a == a); }
@@ -135,15 +146,25 @@ struct DimsP {
     int nG, nL, cb, p2G, p2L, shared_grid;
 };
 
-template <typename T> struct FwdP {
-    DimsP d;
-    const T *U, *V, *Tm, *SH, *QL, *QI, *Pf, *Ph, *Zgfull, *Zghalf, *zf, *zh;
-    const T *u_d, *v_d, *thl_d, *qt_d, *ql_d, *ps_d, *rain, *rain_last;
-    T factor, dt;
-    T *f_u, *f_v, *f_thl, *f_qt, *f_ql, *ql_ref, *f_ps, *u, *v, *thl, *qt, *ps, *Zf, *Zh, *rainrate;
-    int32_t *idx;
+struct Empty {};
+
+// optional outputs / surface coupling of the forward pass: only in the FULL kernel variant, so that the
+// lean hot-path variant keeps its ~26 pointers in SGPRs without spilling
+template <typename T> struct FwdOpt {
+    const T *rain, *rain_last;
+    T *u, *v, *thl, *qt, *ps, *Zf, *Zh, *rainrate;
     const T *Z0M, *Z0H, *QLflux, *QIflux, *SHflux, *TSflux;
     T *z0m, *z0h, *wthl, *wqt;
+};
+
+template <typename T, bool FULL> struct FwdP {
+    DimsP d;
+    const T *U, *V, *Tm, *SH, *QL, *QI, *Pf, *Ph, *Zgfull, *Zghalf, *zf, *zh;
+    const T *u_d, *v_d, *thl_d, *qt_d, *ql_d, *ps_d;
+    T factor, dt;
+    T *f_u, *f_v, *f_thl, *f_qt, *f_ql, *ql_ref, *f_ps;
+    int32_t *idx;
+    typename std::conditional<FULL, FwdOpt<T>, Empty>::type o;
 };
 
 template <typename T> struct BwdP {
@@ -163,13 +184,42 @@ template <typename T> struct DiagP {
 
 extern __shared__ __align__(16) unsigned char spc_smem[];
 
+// Diagnostic build only (-DSPC_STAMPS, tools/stamps.py): thread 0 of each workgroup drains its memory
+// counters and writes the 100 MHz wall clock at phase boundaries into a buffer no kernel code reads.
+#ifdef SPC_STAMPS
+__device__ unsigned long long *g_stamps = nullptr;
+#define STAMP(i)                                                                     \
+    do {                                                                             \
+        if (threadIdx.x == 0 && g_stamps) {                                          \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");              \
+            g_stamps[(size_t)blockIdx.x * 8 + (i)] = wall_clock64();                 \
+        }                                                                            \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 // =================================================================================================
 // K1 forward: splib/spcpl.py:171-246 (convert_profiles) + 299-385 (set_les_forcings) for CB columns
 // per workgroup; optional fused K2 (spcpl.py:764) and surface fluxes (spcpl.py:136-167).
 // LDS per column: xp=Zf reversed | thl_ | qt_ | QL | U | V, each [nG] in ascending-height order;
 // then (idx only) zh: [nL] when the LES grid is shared, else [CB x nL].
 // =================================================================================================
-template <typename T> __global__ __launch_bounds__(BLOCK) void k_forward(const FwdP<T> p)
+// LES-side inputs of one output level (loaded early so their latency hides behind phase 1)
+template <typename T> struct LesIn {
+    T h, ud, vd, thld, qtd, qld;
+};
+
+template <typename P, typename T = decltype(+*P().zf)>
+__device__ __forceinline__ LesIn<T> load_les(const P &p, int l, int64_t o)
+{
+    LesIn<T> r;
+    r.h = p.d.shared_grid ? p.zf[l] : p.zf[o];                                        // spcpl.py:222
+    r.ud = p.u_d[o]; r.vd = p.v_d[o]; r.thld = p.thl_d[o]; r.qtd = p.qt_d[o]; r.qld = p.ql_d[o];
+    return r;
+}
+
+template <typename T, bool FULL> __global__ __launch_bounds__(BLOCK) void k_forward(const FwdP<T, FULL> p)
 {
     const DimsP &d = p.d;
     const int nG = d.nG, nL = d.nL, cb = d.cb;
@@ -178,94 +228,129 @@ template <typename T> __global__ __launch_bounds__(BLOCK) void k_forward(const F
     const int ncol = (int)((d.n_cols - col0) < cb ? (d.n_cols - col0) : cb);
     T *const lds = reinterpret_cast<T *>(spc_smem);
     T *const lzh = lds + (size_t)cb * 6 * nG;
+    // work items after the barrier: [0, n2) LES levels to interpolate, [n2, n2 + nI) index-map entries
+    const int n1 = ncol * nG, n2 = ncol * nL, nI = p.idx ? n1 : 0, nitems = n2 + nI;
+    STAMP(0);
 
-    // ---- phase 1: load GCM levels (flat over the [ncol x nG] slab), convert, stage reversed ----
-    for (int e = tid; e < ncol * nG; e += BLOCK) {
-        const int c = e / nG, k = e - c * nG;
-        const int64_t col = col0 + c, g = col * d.pitchG + k;
-        const T zsurf = p.Zghalf[col * d.pitchGh + nG];
-        const T tt = p.Tm[g], sh = p.SH[g], ql = p.QL[g], qi = p.QI[g];
-        const T zf_k = (p.Zgfull[g] - zsurf) / K<T>::grav;                            // spcpl.py:198
-        const T iex = spc_pow(p.Pf[g] / K<T>::pref0, (-K<T>::rd) / K<T>::cp);         // sputils.py:34
-        const T thl_ = (tt - (K<T>::rlv * (ql + qi)) / K<T>::cp) * iex;               // spcpl.py:214
-        const T qt_ = sh + ql + qi;                                                   // spcpl.py:215
-        T *const s = lds + (size_t)c * 6 * nG + (nG - 1 - k);                         // [::-1], spcpl.py:224
-        s[0] = zf_k;
-        s[nG] = thl_;
-        s[2 * nG] = qt_;
-        s[3 * nG] = ql;
-        s[4 * nG] = p.U[g];
-        s[5 * nG] = p.V[g];
-        if (p.Zf) p.Zf[g] = zf_k;                                                     // spcpl.py:200
+    // ---- prologue: issue every load that depends on nothing, so ONE memory round trip covers the
+    //      GCM slab, this thread's first work item and the per-column scalars ----------------------
+    LesIn<T> pre2 = {};
+    T pre_zgh = T(0), pre_zs = T(0);
+    if (tid < n2) {
+        const int c = tid / nL, l = tid - c * nL;
+        pre2 = load_les<FwdP<T, FULL>, T>(p, l, (col0 + c) * d.pitchL + l);
+    } else if (tid < nitems) {
+        const int ei = tid - n2, c = ei / nG, m = ei - c * nG;
+        const int64_t gh = (col0 + c) * d.pitchGh;
+        pre_zgh = p.Zghalf[gh + (nG - 1 - m)];
+        pre_zs = p.Zghalf[gh + nG];
+    }
+    const int sc = BLOCK - 1 - tid;          // the LAST threads own the per-column scalars
+    T sc_ps = T(0), sc_psd = T(0), sc_rain = T(0), sc_rl = T(0);
+    if (sc < ncol) {
+        sc_ps = p.Ph[(col0 + sc) * d.pitchGh + nG];                                   // spcpl.py:246
+        sc_psd = p.ps_d[col0 + sc];
+        if constexpr (FULL)
+            if (p.o.rainrate) { sc_rain = p.o.rain[col0 + sc]; sc_rl = p.o.rain_last[col0 + sc]; }
     }
     if (p.idx) {  // stage the LES half levels for the fused index map
-        const int nz = d.shared_grid ? nL : ncol * nL;
+        const int nz = d.shared_grid ? nL : n2;
         for (int e = tid; e < nz; e += BLOCK) {
             const int c = e / nL, l = e - c * nL;
             lzh[e] = d.shared_grid ? p.zh[e] : p.zh[(col0 + c) * d.pitchL + l];
         }
     }
+    STAMP(1);
+
+    // ---- phase 1: load GCM levels (flat over the [ncol x nG] slab), convert, stage reversed ----
+    for (int e = tid; e < n1; e += BLOCK) {
+        const int c = e / nG, k = e - c * nG;
+        const int64_t col = col0 + c, g = col * d.pitchG + k;
+        const T zsurf = p.Zghalf[col * d.pitchGh + nG];
+        const T tt = p.Tm[g], sh = p.SH[g], ql = p.QL[g], qi = p.QI[g], pf = p.Pf[g], zg = p.Zgfull[g];
+        const T uu = p.U[g], vv = p.V[g];
+        const T zf_k = div_grav(zg - zsurf);                                          // spcpl.py:198
+        T *const s = lds + (size_t)c * 6 * nG + (nG - 1 - k);                         // [::-1], spcpl.py:224
+        s[0] = zf_k;
+        s[2 * nG] = sh + ql + qi;                                                     // spcpl.py:215
+        s[3 * nG] = ql;
+        s[4 * nG] = uu;
+        s[5 * nG] = vv;
+        if constexpr (FULL)
+            if (p.o.Zf) p.o.Zf[g] = zf_k;                                             // spcpl.py:200
+        const T iex = spc_pow(div_pref0(pf), (-K<T>::rd) / K<T>::cp);                 // sputils.py:34
+        s[nG] = (tt - div_cp(K<T>::rlv * (ql + qi))) * iex;                           // spcpl.py:214
+    }
+    STAMP(2);
     __syncthreads();
+    STAMP(3);
 
-    // ---- phase 2: every LES level of the slab: interpolate 5 fields, form the forcings ----------
-    for (int e = tid; e < ncol * nL; e += BLOCK) {
-        const int c = e / nL, l = e - c * nL;
-        const int64_t col = col0 + c, o = col * d.pitchL + l;
-        const T *const s = lds + (size_t)c * 6 * nG;
-        const T h = d.shared_grid ? p.zf[l] : p.zf[o];                                // spcpl.py:222
-        const T ud = p.u_d[o], vd = p.v_d[o], thld = p.thl_d[o], qtd = p.qt_d[o], qld = p.ql_d[o];
-        const Bracket<T> b = bracket(s, nG, d.p2G, h);
-        const T thl = interp_at(b, s + nG);                                           // spcpl.py:224
-        const T qt = interp_at(b, s + 2 * nG);                                        // spcpl.py:225
-        const T ql = interp_at(b, s + 3 * nG);                                        // spcpl.py:226
-        const T u = interp_at(b, s + 4 * nG);                                         // spcpl.py:227
-        const T v = interp_at(b, s + 5 * nG);                                         // spcpl.py:228
-        p.f_u[o] = p.factor * (u - ud) / p.dt;                                        // spcpl.py:328
-        p.f_v[o] = p.factor * (v - vd) / p.dt;                                        // spcpl.py:329
-        p.f_thl[o] = p.factor * (thl - thld) / p.dt;                                  // spcpl.py:330
-        p.f_qt[o] = p.factor * (qt - qtd) / p.dt;                                     // spcpl.py:331
-        p.f_ql[o] = p.factor * (ql - qld) / p.dt;                                     // spcpl.py:333
-        p.ql_ref[o] = ql;                                                             // spcpl.py:347-348
-        if (p.u) p.u[o] = u;
-        if (p.v) p.v[o] = v;
-        if (p.thl) p.thl[o] = thl;
-        if (p.qt) p.qt[o] = qt;
-    }
-
-    // ---- per-column scalars ------------------------------------------------------------------
-    if (tid < ncol) {
-        const int64_t col = col0 + tid;
-        const T ps = p.Ph[col * d.pitchGh + nG];                                      // spcpl.py:246
-        p.f_ps[col] = p.factor * (ps - p.ps_d[col]) / p.dt;                           // spcpl.py:332
-        if (p.ps) p.ps[col] = ps;
-        if (p.rainrate) p.rainrate[col] = (p.rain[col] - p.rain_last[col]) / p.dt;    // spcpl.py:325
-        if (p.wthl) {                                                                 // spcpl.py:136-167
-            const T rho = ps / (K<T>::rd * p.Tm[col * d.pitchG + nG - 1]);            // spcpl.py:153
-            p.wqt[col] = -(p.QLflux[col] + p.QIflux[col] + p.SHflux[col]) / rho;      // spcpl.py:159
-            p.wthl[col] = -p.TSflux[col] * spc_pow(ps / K<T>::pref0, (-K<T>::rd) / K<T>::cp)
-                          / (K<T>::cp * rho);                                         // spcpl.py:161
-            if (p.z0m) p.z0m[col] = p.Z0M[col];
-            if (p.z0h) p.z0h[col] = p.Z0H[col];
+    // ---- per-column scalars (inputs already in registers; stores drain behind phase 2) ----------
+    if (sc < ncol) {
+        const int64_t col = col0 + sc;
+        p.f_ps[col] = p.factor * (sc_ps - sc_psd) / p.dt;          // spcpl.py:332
+        if constexpr (FULL) {
+            if (p.o.ps) p.o.ps[col] = sc_ps;
+            if (p.o.rainrate) p.o.rainrate[col] = (sc_rain - sc_rl) / p.dt;   // spcpl.py:325
+            if (p.o.wthl) {                                                            // spcpl.py:136-167
+                const T rho = sc_ps / (K<T>::rd * p.Tm[col * d.pitchG + nG - 1]);      // spcpl.py:153
+                p.o.wqt[col] = -(p.o.QLflux[col] + p.o.QIflux[col] + p.o.SHflux[col]) / rho;     // spcpl.py:159
+                p.o.wthl[col] = -p.o.TSflux[col] * spc_pow(div_pref0(sc_ps), (-K<T>::rd) / K<T>::cp)
+                                / (K<T>::cp * rho);                                    // spcpl.py:161
+                if (p.o.z0m) p.o.z0m[col] = p.o.Z0M[col];
+                if (p.o.z0h) p.o.z0h[col] = p.o.Z0H[col];
+            }
         }
     }
 
-    // ---- half-level heights and fused index map (K2): spcpl.py:197, 764 -------------------------
-    if (p.Zh) {
-        for (int e = tid; e < ncol * (nG + 1); e += BLOCK) {
-            const int c = e / (nG + 1), k = e - c * (nG + 1);
-            const int64_t gh = (col0 + c) * d.pitchGh;
-            p.Zh[gh + k] = (p.Zghalf[gh + k] - p.Zghalf[gh + nG]) / K<T>::grav;
-        }
-    }
-    if (p.idx) {
-        for (int e = tid; e < ncol * nG; e += BLOCK) {
-            const int c = e / nG, m = e - c * nG;
+    // ---- phase 2: LES levels (interpolate 5 fields, form the forcings) and index-map entries ------
+    for (int e = tid; e < nitems; e += BLOCK) {
+        if (e < n2) {
+            const int c = e / nL, l = e - c * nL;
+            const int64_t col = col0 + c, o = col * d.pitchL + l;
+            const T *const s = lds + (size_t)c * 6 * nG;
+            const LesIn<T> in = (e == tid) ? pre2 : load_les<FwdP<T, FULL>, T>(p, l, o);
+            const Bracket<T> b = bracket(s, nG, d.p2G, in.h);
+            const T thl = interp_at(b, s + nG);                                       // spcpl.py:224
+            const T qt = interp_at(b, s + 2 * nG);                                    // spcpl.py:225
+            const T ql = interp_at(b, s + 3 * nG);                                    // spcpl.py:226
+            const T u = interp_at(b, s + 4 * nG);                                     // spcpl.py:227
+            const T v = interp_at(b, s + 5 * nG);                                     // spcpl.py:228
+            p.f_u[o] = p.factor * (u - in.ud) / p.dt;               // spcpl.py:328
+            p.f_v[o] = p.factor * (v - in.vd) / p.dt;               // spcpl.py:329
+            p.f_thl[o] = p.factor * (thl - in.thld) / p.dt;         // spcpl.py:330
+            p.f_qt[o] = p.factor * (qt - in.qtd) / p.dt;            // spcpl.py:331
+            p.f_ql[o] = p.factor * (ql - in.qld) / p.dt;            // spcpl.py:333
+            p.ql_ref[o] = ql;                                                         // spcpl.py:347-348
+            if constexpr (FULL) {
+                if (p.o.u) p.o.u[o] = u;
+                if (p.o.v) p.o.v[o] = v;
+                if (p.o.thl) p.o.thl[o] = thl;
+                if (p.o.qt) p.o.qt[o] = qt;
+            }
+        } else {                                                                      // fused K2, spcpl.py:764
+            const int ei = e - n2, c = ei / nG, m = ei - c * nG;
             const int64_t col = col0 + c, gh = col * d.pitchGh;
-            const T Zh_k = (p.Zghalf[gh + (nG - 1 - m)] - p.Zghalf[gh + nG]) / K<T>::grav;
+            const T zgh = (e == tid) ? pre_zgh : p.Zghalf[gh + (nG - 1 - m)];
+            const T zs = (e == tid) ? pre_zs : p.Zghalf[gh + nG];
+            const T Zh_k = div_grav(zgh - zs);                                        // spcpl.py:197
             const T *const zh = d.shared_grid ? lzh : lzh + (size_t)c * nL;
             p.idx[col * d.pitchG + m] = ss_right(zh, nL, Zh_k);
         }
     }
+    STAMP(4);
+
+    // ---- half-level heights (optional output): spcpl.py:197 --------------------------------------
+    if constexpr (FULL) {
+        if (p.o.Zh) {
+            for (int e = tid; e < ncol * (nG + 1); e += BLOCK) {
+                const int c = e / (nG + 1), k = e - c * (nG + 1);
+                const int64_t gh = (col0 + c) * d.pitchGh;
+                p.o.Zh[gh + k] = div_grav(p.Zghalf[gh + k] - p.Zghalf[gh + nG]);
+            }
+        }
+    }
+    STAMP(5);
 }
 
 // =================================================================================================
@@ -297,6 +382,18 @@ __global__ __launch_bounds__(BLOCK) void k_cloud_idx(const DimsP d, const T *zh_
 // (518-526) + masking (527-533).  LDS per column: t | qt | ql | ql_ice | u | v, each [nL]; then
 // Zf [nG]; then h: [nL] when the LES grid is shared, else [CB x nL].
 // =================================================================================================
+template <typename T> struct GcmIn {
+    T tt, sh, ql, qi, u, v, a, a_d;
+};
+
+template <typename T> __device__ __forceinline__ GcmIn<T> load_gcm(const BwdP<T> &p, int64_t g, int64_t g_rev)
+{
+    GcmIn<T> r;
+    r.tt = p.Tm[g]; r.sh = p.SH[g]; r.ql = p.QL[g]; r.qi = p.QI[g]; r.u = p.U[g]; r.v = p.V[g]; r.a = p.A[g];
+    r.a_d = p.A_prof[g_rev];                                                           // spcpl.py:404
+    return r;
+}
+
 template <typename T> __global__ __launch_bounds__(BLOCK) void k_backward(const BwdP<T> p)
 {
     const DimsP &d = p.d;
@@ -306,6 +403,15 @@ template <typename T> __global__ __launch_bounds__(BLOCK) void k_backward(const 
     const size_t per_col = (size_t)6 * nL + nG;
     T *const lds = reinterpret_cast<T *>(spc_smem);
     T *const lh = lds + (size_t)cb * per_col;
+    const int n1 = ncol * nG;
+
+    // prologue: GCM-side inputs of this thread's first output level, in flight during the staging
+    GcmIn<T> pre = {};
+    if (tid < n1) {
+        const int c = tid / nG, k = tid - c * nG;
+        const int64_t cg = (col0 + c) * d.pitchG;
+        pre = load_gcm(p, cg + k, cg + (nG - 1 - k));
+    }
 
     for (int e = tid; e < ncol * nL; e += BLOCK) {
         const int c = e / nL, l = e - c * nL;
@@ -321,23 +427,22 @@ template <typename T> __global__ __launch_bounds__(BLOCK) void k_backward(const 
     }
     if (d.shared_grid)
         for (int e = tid; e < nL; e += BLOCK) lh[e] = p.zf[e];
-    for (int e = tid; e < ncol * nG; e += BLOCK) {
+    for (int e = tid; e < n1; e += BLOCK) {
         const int c = e / nG, k = e - c * nG;
         const int64_t col = col0 + c, g = col * d.pitchG + k;
         const T zf_k = p.Zf ? p.Zf[g]
-                            : (p.Zgfull[g] - p.Zghalf[col * d.pitchGh + nG]) / K<T>::grav;  // spcpl.py:198
+                            : div_grav(p.Zgfull[g] - p.Zghalf[col * d.pitchGh + nG]);       // spcpl.py:198
         lds[(size_t)c * per_col + 6 * nL + k] = zf_k;
     }
     __syncthreads();
 
-    for (int e = tid; e < ncol * nG; e += BLOCK) {
+    for (int e = tid; e < n1; e += BLOCK) {
         const int c = e / nG, k = e - c * nG;
-        const int64_t col = col0 + c, g = col * d.pitchG + k;
+        const int64_t col = col0 + c, cg = col * d.pitchG, g = cg + k;
         const T *const s = lds + (size_t)c * per_col;
         const T *const h = d.shared_grid ? lh : lh + (size_t)c * nL;
         const T *const Zf = s + 6 * nL;
-        const T tt = p.Tm[g], sh = p.SH[g], qlg = p.QL[g], qig = p.QI[g], ug = p.U[g], vg = p.V[g], ag = p.A[g];
-        const T a_d = p.A_prof[col * d.pitchG + (nG - 1 - k)];                         // spcpl.py:404
+        const GcmIn<T> in = (e == tid) ? pre : load_gcm(p, g, cg + (nG - 1 - k));
         const T x = Zf[k];
         const int start_index = ss_left_neg(Zf, nG, h[nL - 1]);                        // spcpl.py:498
         const Bracket<T> b = bracket(h, nL, d.p2L, x);
@@ -364,13 +469,13 @@ template <typename T> __global__ __launch_bounds__(BLOCK) void k_backward(const 
         } else {
             t_i = qt_i = ql_i = qlw_i = qli_i = u_i = v_i = x;
         }
-        T f_T = p.factor * (t_i - tt) / p.dt;                                          // spcpl.py:518
-        T f_SH = p.factor * ((qt_i - ql_i) - sh) / p.dt;                               // spcpl.py:519
-        T f_QL = p.factor * (qlw_i - qlg) / p.dt;                                      // spcpl.py:520
-        T f_QI = p.factor * (qli_i - qig) / p.dt;                                      // spcpl.py:521
-        T f_U = p.factor * (u_i - ug) / p.dt;                                          // spcpl.py:524
-        T f_V = p.factor * (v_i - vg) / p.dt;                                          // spcpl.py:525
-        T f_A = p.factor * (a_d - ag) / p.dt;                                          // spcpl.py:526
+        T f_T = p.factor * (t_i - in.tt) / p.dt;                                       // spcpl.py:518
+        T f_SH = p.factor * ((qt_i - ql_i) - in.sh) / p.dt;                            // spcpl.py:519
+        T f_QL = p.factor * (qlw_i - in.ql) / p.dt;                                    // spcpl.py:520
+        T f_QI = p.factor * (qli_i - in.qi) / p.dt;                                    // spcpl.py:521
+        T f_U = p.factor * (u_i - in.u) / p.dt;                                        // spcpl.py:524
+        T f_V = p.factor * (v_i - in.v) / p.dt;                                        // spcpl.py:525
+        T f_A = p.factor * (in.a_d - in.a) / p.dt;                                     // spcpl.py:526
         if (k < start_index) {  // `f[0:start_index] *= 0` (spcpl.py:527-533): -x -> -0, NaN stays NaN
             const T zero = T(0);
             f_T *= zero; f_SH *= zero; f_QL *= zero; f_QI *= zero; f_U *= zero; f_V *= zero; f_A *= zero;
@@ -402,9 +507,9 @@ template <typename T> __global__ __launch_bounds__(BLOCK) void k_diag(const Diag
         const int c = e / nG, k = e - c * nG;
         const int64_t col = col0 + c, g = col * d.pitchG + k;
         const T tt = p.Tm[g], sh = p.SH[g], ql = p.QL[g], qi = p.QI[g], pf = p.Pf[g];
-        const T zf_k = (p.Zgfull[g] - p.Zghalf[col * d.pitchGh + nG]) / K<T>::grav;
+        const T zf_k = div_grav(p.Zgfull[g] - p.Zghalf[col * d.pitchGh + nG]);
         if (p.Tv) p.Tv[g] = tt * (T(1) + cc * sh - (ql + qi));                          // spcpl.py:176
-        if (p.THL) p.THL[g] = (tt - (K<T>::rlv * (ql + qi)) / K<T>::cp) * spc_pow(pf / K<T>::pref0, (-K<T>::rd) / K<T>::cp);
+        if (p.THL) p.THL[g] = (tt - div_cp(K<T>::rlv * (ql + qi))) * spc_pow(div_pref0(pf), (-K<T>::rd) / K<T>::cp);
         if (p.QT) p.QT[g] = sh + ql + qi;
         if (p.Zf) p.Zf[g] = zf_k;
         T *const s = lds + (size_t)c * 2 * nG + (nG - 1 - k);
@@ -415,7 +520,7 @@ template <typename T> __global__ __launch_bounds__(BLOCK) void k_diag(const Diag
         for (int e = tid; e < ncol * (nG + 1); e += BLOCK) {
             const int c = e / (nG + 1), k = e - c * (nG + 1);
             const int64_t gh = (col0 + c) * d.pitchGh;
-            p.Zh[gh + k] = (p.Zghalf[gh + k] - p.Zghalf[gh + nG]) / K<T>::grav;         // spcpl.py:197
+            p.Zh[gh + k] = div_grav(p.Zghalf[gh + k] - p.Zghalf[gh + nG]);         // spcpl.py:197
         }
     }
     __syncthreads();
@@ -429,7 +534,7 @@ template <typename T> __global__ __launch_bounds__(BLOCK) void k_diag(const Diag
             const T pf = interp_at(b, s + nG);                                         // spcpl.py:408
             if (p.pf) p.pf[o] = pf;
             if (p.t)                                                                   // spcpl.py:409
-                p.t[o] = p.thl_d[o] * spc_pow(pf / K<T>::pref0, K<T>::rd / K<T>::cp) + K<T>::rlv * p.ql_d[o] / K<T>::cp;
+                p.t[o] = p.thl_d[o] * spc_pow(div_pref0(pf), K<T>::rd / K<T>::cp) + div_cp(K<T>::rlv * p.ql_d[o]);
             if (p.ql_water) p.ql_water[o] = p.ql_d[o] - p.ql_ice_d[o];                  // spcpl.py:402
         }
     }
@@ -478,18 +583,45 @@ void lds_elems(const spc_dims *d, int pass, bool with_idx, size_t *per_col, size
     }
 }
 
-// Columns per workgroup: as many as keeps >= 8 workgroups per CU in flight (256 CUs), within LDS.
-int pick_cb(const spc_dims *d, int pass, bool with_idx, size_t esize)
+// Resident workgroups per CU for `kernel` with `smem` bytes of dynamic LDS (occupancy API, cached).
+// Without a device (CPU-side ABI tests) falls back to min(4, 160 KiB / smem).
+template <typename KernelT> int blocks_per_cu(KernelT kernel, size_t smem)
+{
+    thread_local std::unordered_map<uint64_t, int> cache;
+    const uint64_t key = (uint64_t)(uintptr_t)kernel * 1000003u + smem;
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, BLOCK, smem) != hipSuccess || nb <= 0) {
+        (void)hipGetLastError();
+        const size_t by_lds = smem ? (size_t)(160 * 1024) / smem : 8;
+        nb = (int)(by_lds < 4 ? by_lds : 4);
+    }
+    if (nb > 8) nb = 8;
+    cache[key] = nb;
+    return nb;
+}
+
+// Columns per workgroup.  Small batches: one column per workgroup (latency-bound, maximum parallelism).
+// Large batches (>= 2048 workgroups left): the candidate in {8,4,2,1} with the most resident
+// workgroups per CU (LDS- and register-limited), ties to the larger one (longer coalesced slabs).
+template <typename KernelT> int pick_cb(const spc_dims *d, int pass, bool with_idx, size_t esize, KernelT kernel)
 {
     size_t per_col, fixed;
     lds_elems(d, pass, with_idx, &per_col, &fixed);
     int cb = d->cols_per_block;
-    if (cb <= 0) {
-        cb = 8;
-        while (cb > 1 && d->n_cols / cb < 2048) cb >>= 1;
+    if (cb > 0) {
+        while (cb > 1 && (per_col * cb + fixed) * esize > (size_t)MAX_LDS_BYTES) --cb;
+        return cb;
     }
-    while (cb > 1 && (per_col * cb + fixed) * esize > (size_t)MAX_LDS_BYTES) --cb;
-    return cb;
+    int best = 1, best_nb = -1;
+    for (cb = 8; cb >= 1; cb >>= 1) {
+        const size_t smem = (per_col * cb + fixed) * esize;
+        if (cb > 1 && (d->n_cols / cb < 2048 || smem > (size_t)MAX_LDS_BYTES)) continue;
+        const int nb = blocks_per_cu(kernel, smem);
+        if (nb > best_nb) { best_nb = nb; best = cb; }
+    }
+    return best;
 }
 
 DimsP make_dims(const spc_dims *d, int cb)
@@ -534,24 +666,37 @@ template <typename T> int forward_impl(const spc_dims *d, const spc_forward_args
             return fail(SPC_ERR_INVALID_ARGUMENT, "%sz0m/z0h requested but Z0M/Z0H is NULL");
     }
     const bool with_idx = a->idx != nullptr;
-    const int cb = pick_cb(d, 0, with_idx, sizeof(T));
+    const bool full = a->u || a->v || a->thl || a->qt || a->ps || a->Zf || a->Zh || a->rainrate || a->wthl;
+    const int cb = full ? pick_cb(d, 0, with_idx, sizeof(T), k_forward<T, true>)
+                        : pick_cb(d, 0, with_idx, sizeof(T), k_forward<T, false>);
     size_t per_col, fixed;
     lds_elems(d, 0, with_idx, &per_col, &fixed);
     const size_t smem = (per_col * cb + fixed) * sizeof(T);
     if (smem > (size_t)MAX_LDS_BYTES)
         return fail(SPC_ERR_UNSUPPORTED, "%sforward needs %lld B of LDS per workgroup (max %lld)", "", (long long)smem, MAX_LDS_BYTES);
-    FwdP<T> p;
-    p.d = make_dims(d, cb);
 #define CP(f) p.f = (const T *)a->f
 #define OP(f) p.f = (T *)a->f
-    CP(U); CP(V); p.Tm = (const T *)a->T; CP(SH); CP(QL); CP(QI); CP(Pf); CP(Ph); CP(Zgfull); CP(Zghalf); CP(zf); CP(zh);
-    CP(u_d); CP(v_d); CP(thl_d); CP(qt_d); CP(ql_d); CP(ps_d); CP(rain); CP(rain_last);
-    p.factor = (T)a->factor; p.dt = (T)a->dt;
-    OP(f_u); OP(f_v); OP(f_thl); OP(f_qt); OP(f_ql); OP(ql_ref); OP(f_ps); OP(u); OP(v); OP(thl); OP(qt); OP(ps);
-    OP(Zf); OP(Zh); OP(rainrate); p.idx = a->idx;
-    CP(Z0M); CP(Z0H); CP(QLflux); CP(QIflux); CP(SHflux); CP(TSflux); OP(z0m); OP(z0h); OP(wthl); OP(wqt);
+#define COP(f) p.o.f = (const T *)a->f
+#define OOP(f) p.o.f = (T *)a->f
     const unsigned grid = (unsigned)((d->n_cols + cb - 1) / cb);
-    hipLaunchKernelGGL(k_forward<T>, dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
+    auto fill = [&](auto &p) {
+        p.d = make_dims(d, cb);
+        CP(U); CP(V); p.Tm = (const T *)a->T; CP(SH); CP(QL); CP(QI); CP(Pf); CP(Ph); CP(Zgfull); CP(Zghalf);
+        CP(zf); CP(zh); CP(u_d); CP(v_d); CP(thl_d); CP(qt_d); CP(ql_d); CP(ps_d);
+        p.factor = (T)a->factor; p.dt = (T)a->dt;
+        OP(f_u); OP(f_v); OP(f_thl); OP(f_qt); OP(f_ql); OP(ql_ref); OP(f_ps); p.idx = a->idx;
+    };
+    if (full) {
+        FwdP<T, true> p;
+        fill(p);
+        COP(rain); COP(rain_last); OOP(u); OOP(v); OOP(thl); OOP(qt); OOP(ps); OOP(Zf); OOP(Zh); OOP(rainrate);
+        COP(Z0M); COP(Z0H); COP(QLflux); COP(QIflux); COP(SHflux); COP(TSflux); OOP(z0m); OOP(z0h); OOP(wthl); OOP(wqt);
+        hipLaunchKernelGGL((k_forward<T, true>), dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
+    } else {
+        FwdP<T, false> p;
+        fill(p);
+        hipLaunchKernelGGL((k_forward<T, false>), dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
+    }
     return launch_status("k_forward");
 }
 
@@ -562,7 +707,7 @@ int cloud_idx_impl(const spc_dims *d, const void *zh, const void *Zh, int32_t *i
     if (rc) return rc;
     if (d->n_cols == 0) return SPC_OK;
     REQUIRE(zh, "zh"); REQUIRE(Zh, "Zh"); REQUIRE(idx, "idx");
-    const int cb = pick_cb(d, 2, true, sizeof(T));
+    const int cb = pick_cb(d, 2, true, sizeof(T), k_cloud_idx<T>);
     size_t per_col, fixed;
     lds_elems(d, 2, true, &per_col, &fixed);
     const size_t smem = (per_col * cb + fixed) * sizeof(T);
@@ -589,7 +734,7 @@ template <typename T> int backward_impl(const spc_dims *d, const spc_backward_ar
     REQUIRE(a->f_QI, "f_QI"); REQUIRE(a->f_U, "f_U"); REQUIRE(a->f_V, "f_V"); REQUIRE(a->f_A, "f_A");
     if (!a->Zf && (!a->Zgfull || !a->Zghalf))
         return fail(SPC_ERR_INVALID_ARGUMENT, "%sneither Zf nor (Zgfull, Zghalf) given");
-    const int cb = pick_cb(d, 1, false, sizeof(T));
+    const int cb = pick_cb(d, 1, false, sizeof(T), k_backward<T>);
     size_t per_col, fixed;
     lds_elems(d, 1, false, &per_col, &fixed);
     const size_t smem = (per_col * cb + fixed) * sizeof(T);
@@ -617,7 +762,7 @@ template <typename T> int diag_impl(const spc_dims *d, const spc_diagnostics_arg
     if ((a->pf || a->t || a->ql_water) && !a->zf) return fail(SPC_ERR_INVALID_ARGUMENT, "%sLES diagnostics need zf");
     if (a->t && (!a->thl_d || !a->ql_d)) return fail(SPC_ERR_INVALID_ARGUMENT, "%st needs thl_d and ql_d");
     if (a->ql_water && (!a->ql_d || !a->ql_ice_d)) return fail(SPC_ERR_INVALID_ARGUMENT, "%sql_water needs ql_d and ql_ice_d");
-    const int cb = pick_cb(d, 3, false, sizeof(T));
+    const int cb = pick_cb(d, 3, false, sizeof(T), k_diag<T>);
     size_t per_col, fixed;
     lds_elems(d, 3, false, &per_col, &fixed);
     const size_t smem = (per_col * cb + fixed) * sizeof(T);
@@ -633,6 +778,8 @@ template <typename T> int diag_impl(const spc_dims *d, const spc_diagnostics_arg
 }
 #undef CP
 #undef OP
+#undef COP
+#undef OOP
 
 }  // namespace
 
@@ -653,6 +800,13 @@ int spc_backward_f32(const spc_dims *d, const spc_backward_args *a, void *s) { r
 int spc_diagnostics_f64(const spc_dims *d, const spc_diagnostics_args *a, void *s) { return diag_impl<double>(d, a, s); }
 int spc_diagnostics_f32(const spc_dims *d, const spc_diagnostics_args *a, void *s) { return diag_impl<float>(d, a, s); }
 
+#ifdef SPC_STAMPS
+int spc_debug_set_stamps(void *buf)  // diagnostic build only
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : SPC_ERR_LAUNCH;
+}
+#endif
+
 int spc_abi_version(void) { return SPC_ABI_VERSION; }
 const char *spc_last_error(void) { return g_err; }
 
@@ -670,8 +824,13 @@ int spc_pick_cols_per_block(const spc_dims *d, int pass)
 {
     int rc = validate(d);
     if (rc) return rc;
-    if (pass < 0 || pass > 3) return fail(SPC_ERR_INVALID_ARGUMENT, "%spass must be 0..3");
-    return pick_cb(d, pass, pass == 0 || pass == 2, sizeof(double));
+    switch (pass) {
+    case 0: return pick_cb(d, 0, true, sizeof(double), k_forward<double, false>);
+    case 1: return pick_cb(d, 1, false, sizeof(double), k_backward<double>);
+    case 2: return pick_cb(d, 2, true, sizeof(double), k_cloud_idx<double>);
+    case 3: return pick_cb(d, 3, false, sizeof(double), k_diag<double>);
+    default: return fail(SPC_ERR_INVALID_ARGUMENT, "%spass must be 0..3");
+    }
 }
 
 int spc_stream_copy(void *dst, const void *src, int64_t bytes, void *stream)

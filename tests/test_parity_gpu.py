@@ -238,3 +238,4 @@ def test_layout_and_argument_errors(eng):
     pe = {k: v[:0] for k, v in p.items()}
     out = eng.forward(e, zf_d, pe, 1.0, DT)
     assert out["f_u"].shape == (0, 160)
+

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmark: average duration of K1 / K3 alone over rotating batches, for several
+batch sizes and cols_per_block settings (HIP events around M back-to-back launches).
+Usage: python tools/kbench.py [--sizes 1024,35718] [--cbs 0,1,2,4,8] [--levels 91,160]"""
+import argparse
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from sp_coupler_amd import synthetic  # noqa: E402
+from sp_coupler_amd.engine import Engine  # noqa: E402
+
+
+def bytes_model(nG, nL):
+    fwd = (9 * nG + 6 * nL + 3) * 8 + (6 * nL + 1) * 8 + nL * 8 + nG * 4
+    bwd = (9 * nG + 7 * nL) * 8 + 7 * nG * 8
+    return fwd, bwd
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sizes", default="1024,35718")
+    ap.add_argument("--cbs", default="0")
+    ap.add_argument("--levels", default="91,160")
+    ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--dtype", default="f64")
+    ap.add_argument("--tag", default="")
+    a = ap.parse_args()
+    nG, nL = (int(x) for x in a.levels.split(","))
+    dtype = torch.float64 if a.dtype == "f64" else torch.float32
+    eng = Engine("cuda:0", dtype=dtype)
+    stream = torch.cuda.current_stream()
+    sptr = ctypes.c_void_p(stream.cuda_stream)
+    fb, bb = bytes_model(nG, nL)
+    if dtype == torch.float32:
+        fb, bb = fb // 2, bb // 2
+    for n in (int(x) for x in a.sizes.split(",")):
+        live = n * (fb + bb)
+        rot = max(2, min(16, int(600e6 // live) + 1))
+        data = []
+        for r in range(rot):
+            gcm, zf, zh, prof = synthetic.make_batch(n, nG, nL, seed=100 + r, couple_surface=False)
+            g = {k: torch.from_numpy(v).to(eng.device, dtype) for k, v in gcm.items()}
+            p = {k: torch.from_numpy(v).to(eng.device, dtype) for k, v in prof.items()}
+            data.append((g, torch.from_numpy(zf).to(eng.device, dtype), torch.from_numpy(zh).to(eng.device, dtype), p))
+        for cb in (int(x) for x in a.cbs.split(",")):
+            fpl = [eng.plan_forward(g, zf, p, 1.0, 900.0, zh=zh, want_heights=False, cols_per_block=cb) for g, zf, zh, p in data]
+            bpl = [eng.plan_backward(g, zf, p, 1.0, 900.0, want_start_index=False, cols_per_block=cb) for g, zf, zh, p in data]
+            res = {}
+            for name, plans in (("K1", fpl), ("K3", bpl)):
+                for i in range(20):
+                    plans[i % rot].launch_raw(sptr)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for i in range(a.iters):
+                    plans[i % rot].launch_raw(sptr)
+                e1.record(stream)
+                torch.cuda.synchronize()
+                res[name] = e0.elapsed_time(e1) * 1e3 / a.iters
+            print("%s n=%d %d<->%d %s cb=%d rot=%d | K1 %.2f us %.0f GB/s (%.1f%% of 8TB/s) | K3 %.2f us %.0f GB/s (%.1f%%)" % (
+                a.tag, n, nG, nL, a.dtype, cb, rot, res["K1"], n * fb / res["K1"] / 1e3, n * fb / res["K1"] / 1e3 / 80,
+                res["K3"], n * bb / res["K3"] / 1e3, n * bb / res["K3"] / 1e3 / 80), flush=True)
+
+
+if __name__ == "__main__":
+    main()

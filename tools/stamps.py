@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Diagnostic: where K1's time goes at small batches. Builds a -DSPC_STAMPS variant of the library
+(never shipped), runs K1 once warm, prints per-phase medians from in-kernel 100 MHz wall-clock stamps."""
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+lib = "/tmp/libspc_stamps.so"
+subprocess.run([ge.HIPCC] + ge.HIP_FLAGS + ["-DSPC_STAMPS", ge.HIP_SRC, "-o", lib], check=True)
+os.environ["SPC_LIB"] = lib
+import numpy  # noqa: E402
+import torch  # noqa: E402
+
+from sp_coupler_amd import synthetic  # noqa: E402
+from sp_coupler_amd.engine import Engine  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+cb = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+eng = Engine("cuda:0")
+eng.lib.spc_debug_set_stamps.argtypes = [ctypes.c_void_p]
+plans = []
+for r in range(8):
+    gcm, zf, zh, prof = synthetic.make_batch(n, 91, 160, seed=r, couple_surface=False)
+    g = {k: torch.from_numpy(v).cuda() for k, v in gcm.items()}
+    p = {k: torch.from_numpy(v).cuda() for k, v in prof.items()}
+    plans.append(eng.plan_forward(g, torch.from_numpy(zf).cuda(), p, 1.0, 900.0, zh=torch.from_numpy(zh).cuda(),
+                                  want_heights=False, cols_per_block=cb))
+nblk = (n + max(cb, 1) - 1) // max(cb, 1) if cb else n
+stamps = torch.zeros(n * 8, dtype=torch.int64, device="cuda")
+for i in range(16):
+    plans[i % 8].launch()
+torch.cuda.synchronize()
+assert eng.lib.spc_debug_set_stamps(stamps.data_ptr()) == 0
+plans[3].launch()
+torch.cuda.synchronize()
+st = stamps.cpu().numpy().reshape(n, 8)
+st = st[st[:, 0] > 0][:, :6].astype(numpy.float64) * 10.0   # ns
+t0 = st[:, 0].min()
+names = ["entry", "prologue loads landed", "phase1 done (pow, LDS)", "barrier passed",
+         "phase2+idx done (stores landed)", "end"]
+print("blocks stamped:", len(st), " kernel span (first entry -> last end): %.2f us" % ((st[:, 5].max() - t0) / 1e3))
+print("entry spread: %.2f us" % ((st[:, 0].max() - t0) / 1e3))
+for i, nm in enumerate(names):
+    d = st[:, i] - (st[:, i - 1] if i else t0)
+    print("%-30s median +%.2f us  (p10 %.2f, p90 %.2f)   abs median %.2f us" % (
+        nm, numpy.median(d) / 1e3, numpy.percentile(d, 10) / 1e3, numpy.percentile(d, 90) / 1e3,
+        numpy.median(st[:, i] - t0) / 1e3))

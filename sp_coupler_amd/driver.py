@@ -1,0 +1,113 @@
+"""Per-step driver: the sequencing of ``splib.step`` / ``step_spinup`` (``splib/splib.py:267-352,
+355-402``) around the batched coupling kernels -- gather -> forcings -> (LES) -> profiles -> tendencies,
+``firststep`` handling, ``profiles`` carry-over and the ``timing.txt`` row.  It drives any pair of
+model objects that satisfy the reference's duck-typed contract (``sp_coupler_amd.models`` ships an
+in-process synthetic pair).  The orchestration around it (process launch, config, restart files) is
+out of scope."""
+import time
+
+from . import spcpl
+from .models import RequestsPool
+
+
+class Coupler:
+    def __init__(self, gcm, les_models, cplsurf=False, les_forcing_factor=1.0, gcm_forcing_factor=1.0,
+                 conservative_coarsening=False, qt_forcing="sp", les_spinup=0, output_column_indices=None, write=False):
+        self.gcm, self.les_models = gcm, list(les_models)
+        self.cplsurf = cplsurf                                   # splib/splib.py:67
+        self.les_forcing_factor = les_forcing_factor             # splib/splib.py:57
+        self.gcm_forcing_factor = gcm_forcing_factor             # splib/splib.py:46
+        self.conservative_coarsening = conservative_coarsening   # splib/splib.py:69
+        self.qt_forcing = qt_forcing                             # splib/splib.py:68
+        self.les_spinup = les_spinup
+        self.output_column_indices = output_column_indices
+        self.write = write
+        self.firststep = True
+        self.profiles = {}
+        self.timing_rows = []                                    # rows of timing.txt (splib/splib.py:340-343)
+        for les in self.les_models:
+            if not hasattr(les, "zf_cache"):
+                les.zh_cache, les.zf_cache = les.get_zh(), les.get_zf()    # splib/splib.py:152-153
+
+    # splib/splib.py:554-594 (async branch): evolve every LES, then fetch its slab means
+    def step_les_models(self, model_time, offset=0):
+        pool = RequestsPool()
+        reqs, profile_reqs = [], {}
+        for les in self.les_models:
+            req = les.evolve_model(model_time + offset, exactEnd=True)
+            reqs.append(req)
+            pool.add_request(req)
+            prof = spcpl.get_les_profiles(les, True)
+            profile_reqs[les] = prof
+            for r in prof.values():
+                pool.add_request(r)
+        pool.waitall()
+        les_profiles = {les: {k: r.result() for k, r in prof.items()} for les, prof in profile_reqs.items()}
+        walls = [r.result() if hasattr(r, "result") else 0.0 for r in reqs]
+        return walls, les_profiles
+
+    # splib/splib.py:267-352
+    def step(self):
+        gcm = self.gcm
+        t = gcm.get_model_time()
+        delta_t = gcm.get_timestep()
+        starttime = time.time()
+        w1 = -time.time()
+        if gcm.first_half_step_done:
+            gcm.first_half_step_done = False
+        else:
+            gcm.evolve_model_until_cloud_scheme()
+            gcm.evolve_model_cloud_scheme()
+        w1 += time.time()
+        gcm.step += 1
+        delta_t = gcm.get_timestep()
+
+        wg = -time.time()
+        spcpl.gather_gcm_data(gcm, self.les_models, self.cplsurf, self.output_column_indices, write=self.write)
+        wg += time.time()
+
+        wf = -time.time()
+        pool = RequestsPool()
+        for req in spcpl.set_les_forcings_batched(self.les_models, gcm, True, self.firststep, self.profiles,
+                                                  dt_gcm=delta_t, factor=self.les_forcing_factor,
+                                                  couple_surface=self.cplsurf, qt_forcing=self.qt_forcing,
+                                                  write=self.write):
+            for r in req.values():
+                pool.add_request(r)
+        pool.waitall()
+        wf += time.time()
+
+        les_wall, self.profiles = self.step_les_models(t + delta_t, offset=self.les_spinup)
+
+        wt = -time.time()
+        spcpl.set_gcm_tendencies_batched(gcm, self.les_models, self.profiles, dt_gcm=delta_t,
+                                         factor=self.gcm_forcing_factor, write=self.write,
+                                         conservative=self.conservative_coarsening)
+        wt += time.time()
+        w2 = -time.time()
+        gcm.evolve_model_from_cloud_scheme()
+        w2 += time.time()
+        self.timing_rows.append((starttime, w1, wg, wf, wt, w2) + tuple(les_wall))
+        self.firststep = False
+
+    # splib/splib.py:355-402 (forcings with dt = spinup length, no GCM tendencies)
+    def step_spinup(self, spinup_length, les_spinup_forcing_factor=1.0):
+        if not self.les_models:
+            return
+        if spcpl.current_batch() is None:
+            spcpl.gather_gcm_data(self.gcm, self.les_models, self.cplsurf, write=self.write)
+        t_les = self.les_models[0].get_model_time()
+        pool = RequestsPool()
+        for req in spcpl.set_les_forcings_batched(self.les_models, self.gcm, True, self.firststep, self.profiles,
+                                                  dt_gcm=spinup_length, factor=les_spinup_forcing_factor,
+                                                  couple_surface=self.cplsurf, qt_forcing=self.qt_forcing,
+                                                  write=self.write):
+            for r in req.values():
+                pool.add_request(r)
+        pool.waitall()
+        _, self.profiles = self.step_les_models(t_les + spinup_length, offset=0)
+        self.firststep = False
+
+    def run(self, nsteps):
+        for _ in range(nsteps):
+            self.step()

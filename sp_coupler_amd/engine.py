@@ -230,7 +230,7 @@ class Engine:
 
     # -- K3 ---------------------------------------------------------------------------------
     def plan_backward(self, gcm, zf, prof, factor, dt, Zf=None, *, want_start_index=True, conservative=False,
-                      cols_per_block=0, out=None):
+                      zh=None, Zh=None, cols_per_block=0, out=None):
         """Arithmetic of set_gcm_tendencies (splib/spcpl.py:388-555) for all columns. ``prof``: dict
         T,QT,QL,QL_ice,U,V [n x nL] and A [n x nG] (order of get_cloudfraction(indices))."""
         T_ = gcm["T"]
@@ -253,6 +253,17 @@ class Engine:
         a.A_prof, pitchG = ck.mat("prof[A]", prof["A"], n, nG, pitchG)
         a.zf, shared = self._grid(ck, "zf", zf, n, nL, pitchL)
         a.conservative = 1 if conservative else 0
+        if conservative:   # sputils.interp_c needs the half levels of both grids and the LES base density
+            if zh is None:
+                raise ValueError("conservative coarsening needs the LES half-level heights zh")
+            a.zh, sh2 = self._grid(ck, "zh", zh, n, nL, pitchL)
+            if sh2 != shared:
+                raise ValueError("zf and zh must both be shared [nL] or both per column [n x nL]")
+            a.rhobf_d, pitchL = ck.mat("prof[Rhobf]", prof["Rhobf"], n, nL, pitchL)
+            if Zh is not None:
+                a.Zh, pitchGh = ck.mat("Zh", Zh, n, nG + 1, pitchGh)
+            else:
+                a.Zghalf, pitchGh = ck.mat("gcm[Zghalf]", gcm["Zghalf"], n, nG + 1, pitchGh)
         a.factor, a.dt = float(factor), float(dt)
         out = dict(out or {})
         res = {}

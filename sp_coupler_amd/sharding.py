@@ -1,0 +1,92 @@
+"""Column sharding across the GPUs of one node.
+
+Every SP column is independent on this path (the reference loops over them independently,
+``splib/splib.py:317,330``; one LES per column, ``splib/splib.py:146``), so the batch is partitioned into
+contiguous row blocks, one per rank / GPU, and each rank runs K1-K3 on its block with NO data-path
+collective.  The only cross-rank step is the host-side gather of result rows on rank 0 for the spifs
+output / setter fan-out (``torch.distributed`` on CPU tensors: gloo; RCCL is used only for the
+benchmark's barrier and max-reduction).  One process per GPU, launched by ``torch.distributed.run``.
+"""
+import numpy
+import torch
+
+
+def shard_bounds(n_cols, world):
+    """row offsets [world+1] of contiguous blocks of ceil(n_cols/world) rows (last blocks may be short/empty)"""
+    per = -(-n_cols // world) if world > 0 else n_cols
+    return [min(r * per, n_cols) for r in range(world + 1)]
+
+
+def shard_range(n_cols, rank, world):
+    b = shard_bounds(n_cols, world)
+    return b[rank], b[rank + 1]
+
+
+def shard_rows(arrays, n_cols, rank, world, replicate=()):
+    """Slice every [n_cols x ...] array of ``arrays`` to this rank's rows; names in ``replicate`` (the
+    shared LES grid) and arrays whose leading extent is not n_cols are passed through whole."""
+    lo, hi = shard_range(n_cols, rank, world)
+    out = {}
+    for k, v in arrays.items():
+        if k in replicate or getattr(v, "ndim", 0) == 0 or v.shape[0] != n_cols:
+            out[k] = v
+        else:
+            out[k] = v[lo:hi]
+    return out
+
+
+def gather_rows(local, n_cols, rank, world, group=None, dst=0):
+    """Host-side concatenation of per-rank row blocks on ``dst`` (returns None elsewhere).
+    ``local``: ndarray [rows_of_this_rank x ...]; uneven blocks are padded to the block size for the
+    collective and trimmed afterwards."""
+    import torch.distributed as dist
+    if world == 1:
+        return numpy.asarray(local)
+    b = shard_bounds(n_cols, world)
+    per = b[1] - b[0]
+    loc = numpy.asarray(local)
+    pad = numpy.zeros((per,) + loc.shape[1:], dtype=loc.dtype)
+    pad[: loc.shape[0]] = loc
+    t = torch.from_numpy(pad)
+    bufs = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
+    dist.gather(t, bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return numpy.concatenate([bufs[r].numpy()[: b[r + 1] - b[r]] for r in range(world)], axis=0)
+
+
+class ShardedExchange:
+    """One rank's share of a column-exchange: forward (K1+K2) and backward (K3) on rows
+    [lo, hi) of the global batch.  ``engine`` is a ``sp_coupler_amd.engine.Engine`` bound to this rank's
+    GPU (tests may inject another object with the same forward/backward methods)."""
+
+    def __init__(self, engine, n_cols, rank, world):
+        self.engine, self.n_cols, self.rank, self.world = engine, n_cols, rank, world
+        self.lo, self.hi = shard_range(n_cols, rank, world)
+
+    def _dev(self, d):
+        dev, dt = self.engine.device, self.engine.dtype
+        return {k: torch.from_numpy(numpy.ascontiguousarray(v)).to(dev, dt) for k, v in d.items()}
+
+    def upload(self, gcm, zf, zh, prof):
+        """host global arrays -> this rank's rows in HBM (grids replicated)"""
+        g = self._dev(shard_rows(gcm, self.n_cols, self.rank, self.world))
+        p = self._dev(shard_rows(prof, self.n_cols, self.rank, self.world))
+        dev, dt = self.engine.device, self.engine.dtype
+        per_col = numpy.ndim(zf) == 2
+        zf_d = torch.from_numpy(numpy.ascontiguousarray(zf[self.lo:self.hi] if per_col else zf)).to(dev, dt)
+        zh_d = torch.from_numpy(numpy.ascontiguousarray(zh[self.lo:self.hi] if per_col else zh)).to(dev, dt)
+        return g, zf_d, zh_d, p
+
+    def exchange(self, g, zf, zh, p, factor_les, factor_gcm, dt):
+        fwd = self.engine.forward(g, zf, p, factor_les, dt, zh=zh, want_heights=True)
+        bwd = self.engine.backward(g, zf, p, factor_gcm, dt, Zf=fwd["Zf"])
+        return fwd, bwd
+
+    def gather(self, results, group=None, dst=0):
+        """dict of device/host row blocks -> dict of full [n_cols x ...] host arrays on ``dst``"""
+        out = {}
+        for k, v in results.items():
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else numpy.asarray(v)
+            out[k] = gather_rows(a, self.n_cols, self.rank, self.world, group, dst)
+        return out if self.rank == dst else None

@@ -151,7 +151,7 @@ int spc_diagnostics_f32(const spc_dims *dims, const spc_diagnostics_args *args, 
 int spc_abi_version(void);          /* == SPC_ABI_VERSION                                          */
 const char *spc_last_error(void);   /* text of the calling thread's last failure ("" if none)     */
 int spc_device_count(void);         /* number of visible HIP devices (0 if none / no driver)      */
-/* columns per workgroup the library would pick for these dims (pass = 0 forward, 1 backward)     */
+/* columns per workgroup the library would pick (pass 0 forward, 1 backward, 2 index, 3 diag, 4 conservative) */
 int spc_pick_cols_per_block(const spc_dims *dims, int pass);
 /* Measured device-to-device copy rate helper for roofline reporting: copies `bytes` from src to
  * dst with a 16 B/lane streaming kernel on `stream`.                                              */

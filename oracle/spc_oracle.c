@@ -172,15 +172,80 @@ int oracle_cloud_indices_f64(const spc_dims *d, const void *zh_, const void *Zh_
     return SPC_OK;
 }
 
-/* splib/spcpl.py:388-555, linear interpolation branch (conservative == 0) */
+/* numpy's pairwise summation of a contiguous double array (DOUBLE_pairwise_sum, numpy/_core/src/umath/
+ * loops_utils.h.src): what `ndarray.sum()` evaluates at splib/sputils.py:144,152,157 */
+static double np_pairwise_sum(const double *a, int64_t n)
+{
+    if (n < 8) {
+        double res = 0.;
+        for (int64_t i = 0; i < n; ++i) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        double r[8], res;
+        int64_t i;
+        for (i = 0; i < 8; ++i) r[i] = a[i];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    } else {
+        int64_t n2 = n / 2;
+        n2 -= n2 % 8;
+        return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+    }
+}
+
+/* sputils.integral with weights (splib/sputils.py:94-161); *ok = 0 where the reference returns None */
+static double integral_w(double a, double b, const double *z, int64_t nz, const double *q, const double *w,
+                         double *tmp, int *ok)
+{
+    *ok = 1;
+    if (a < z[0] || a > z[nz - 1] || b < z[0] || b > z[nz - 1]) { *ok = 0; return 0; }   /* sputils.py:113-115 */
+    double sign = 1;
+    if (a > b) { sign = -1; double t = a; a = b; b = t; }                                /* sputils.py:117-120 */
+    int64_t ia = 0;
+    while (z[ia + 1] < a) ia++;                                                          /* sputils.py:122-124 */
+    int64_t ib = ia;
+    while (z[ib + 1] < b) ib++;                                                          /* sputils.py:125-127 */
+    const int64_t n = ib - ia + 1;
+    for (int64_t i = 0; i < n; ++i) tmp[i] = w[ia + i] * q[ia + i] * (z[ia + i + 1] - z[ia + i]);
+    double S = np_pairwise_sum(tmp, n);                                                  /* sputils.py:152 */
+    double Sa = w[ia] * q[ia] * (a - z[ia]);                                             /* sputils.py:154 */
+    double Sb = w[ib] * q[ib] * (z[ib + 1] - b);                                         /* sputils.py:155 */
+    for (int64_t i = 0; i < n; ++i) tmp[i] = w[ia + i] * (z[ia + i + 1] - z[ia + i]);
+    double Sw = np_pairwise_sum(tmp, n);                                                 /* sputils.py:157 */
+    double Swa = w[ia] * (a - z[ia]);                                                    /* sputils.py:159 */
+    double Swb = w[ib] * (z[ib + 1] - b);                                                /* sputils.py:160 */
+    return (S - Sa - Sb) / (Sw - Swa - Swb) * sign;                                      /* sputils.py:161 */
+}
+
+/* sputils.interp_c (splib/sputils.py:173-189); a None from integral becomes NaN here (the reference
+ * raises on `Q[i] = None`) */
+static void interp_c(const double *Zh, int64_t nG, const double *zh, int64_t nL, const double *q, const double *rho,
+                     double *tmp, double *Q)
+{
+    for (int64_t i = 0; i < nG; ++i) {
+        Q[i] = 0;
+        if (Zh[i] < zh[nL - 1]) {
+            int ok;
+            double v = integral_w(Zh[i + 1], Zh[i], zh, nL, q, rho, tmp, &ok);
+            Q[i] = ok ? v : (0.0 / 0.0);
+        }
+    }
+}
+
+/* splib/spcpl.py:388-555: linear interpolation branch (468-478) or conservative branch (479-489) */
 int oracle_backward_f64(const spc_dims *d, const spc_backward_args *a)
 {
     int rc = check_dims(d);
     if (rc) return rc;
-    if (a->conservative) return SPC_ERR_UNSUPPORTED; /* covered by the NumPy oracle only */
     const int64_t n = d->n_cols, nG = d->nG, nL = d->nL;
     double *Zf = (double *)malloc(sizeof(double) * (size_t)nG);
     double *qlw = (double *)malloc(sizeof(double) * (size_t)nL);
+    double *tmp = (double *)malloc(sizeof(double) * (size_t)nL);
+    double *Zh = (double *)malloc(sizeof(double) * (size_t)(nG + 1));
+    double *Q = (double *)malloc(sizeof(double) * (size_t)nG * 7);
     for (int64_t c = 0; c < n; ++c) {
         const int64_t g = c * d->pitchG, gh = c * d->pitchGh, l = c * d->pitchL;
         const double *h = D(a->zf) + (d->les_grid_shared ? 0 : l);
@@ -193,15 +258,34 @@ int oracle_backward_f64(const spc_dims *d, const spc_backward_args *a)
         for (int64_t i = 0; i < nL; ++i) qlw[i] = D(a->ql_d)[l + i] - D(a->ql_ice_d)[l + i]; /* :402 */
         const int64_t start_index = ss_left_neg(Zf, nG, h[nL - 1]);             /* spcpl.py:498 */
         if (a->start_index) a->start_index[c] = (int32_t)start_index;
+        if (a->conservative) {                                                  /* spcpl.py:482-488 */
+            const double *zh = D(a->zh) + (d->les_grid_shared ? 0 : l);
+            const double *rho = D(a->rhobf_d) + l;
+            if (a->Zh) memcpy(Zh, D(a->Zh) + gh, sizeof(double) * (size_t)(nG + 1));
+            else for (int64_t k = 0; k <= nG; ++k) Zh[k] = (D(a->Zghalf)[gh + k] - D(a->Zghalf)[gh + nG]) / grav;
+            interp_c(Zh, nG, zh, nL, D(a->t_d) + l, rho, tmp, Q);
+            interp_c(Zh, nG, zh, nL, D(a->qt_d) + l, rho, tmp, Q + nG);
+            interp_c(Zh, nG, zh, nL, D(a->ql_d) + l, rho, tmp, Q + 2 * nG);
+            interp_c(Zh, nG, zh, nL, qlw, rho, tmp, Q + 3 * nG);
+            interp_c(Zh, nG, zh, nL, D(a->ql_ice_d) + l, rho, tmp, Q + 4 * nG);
+            interp_c(Zh, nG, zh, nL, D(a->u_d) + l, rho, tmp, Q + 5 * nG);
+            interp_c(Zh, nG, zh, nL, D(a->v_d) + l, rho, tmp, Q + 6 * nG);
+        }
         for (int64_t k = 0; k < nG; ++k) {
             double x = Zf[k];
-            double t_i = interp1(x, h, 1, D(a->t_d) + l, 1, nL);                /* spcpl.py:471 */
-            double qt_i = interp1(x, h, 1, D(a->qt_d) + l, 1, nL);              /* spcpl.py:472 */
-            double ql_i = interp1(x, h, 1, D(a->ql_d) + l, 1, nL);              /* spcpl.py:473 */
-            double qlw_i = interp1(x, h, 1, qlw, 1, nL);                        /* spcpl.py:474 */
-            double qli_i = interp1(x, h, 1, D(a->ql_ice_d) + l, 1, nL);         /* spcpl.py:475 */
-            double u_i = interp1(x, h, 1, D(a->u_d) + l, 1, nL);                /* spcpl.py:476 */
-            double v_i = interp1(x, h, 1, D(a->v_d) + l, 1, nL);                /* spcpl.py:477 */
+            double t_i, qt_i, ql_i, qlw_i, qli_i, u_i, v_i;
+            if (a->conservative) {
+                t_i = Q[k]; qt_i = Q[nG + k]; ql_i = Q[2 * nG + k]; qlw_i = Q[3 * nG + k]; qli_i = Q[4 * nG + k];
+                u_i = Q[5 * nG + k]; v_i = Q[6 * nG + k];
+            } else {
+                t_i = interp1(x, h, 1, D(a->t_d) + l, 1, nL);                   /* spcpl.py:471 */
+                qt_i = interp1(x, h, 1, D(a->qt_d) + l, 1, nL);                 /* spcpl.py:472 */
+                ql_i = interp1(x, h, 1, D(a->ql_d) + l, 1, nL);                 /* spcpl.py:473 */
+                qlw_i = interp1(x, h, 1, qlw, 1, nL);                           /* spcpl.py:474 */
+                qli_i = interp1(x, h, 1, D(a->ql_ice_d) + l, 1, nL);            /* spcpl.py:475 */
+                u_i = interp1(x, h, 1, D(a->u_d) + l, 1, nL);                   /* spcpl.py:476 */
+                v_i = interp1(x, h, 1, D(a->v_d) + l, 1, nL);                   /* spcpl.py:477 */
+            }
             double A_d = D(a->A_prof)[g + nG - 1 - k];                          /* spcpl.py:404 */
             double f_T = a->factor * (t_i - D(a->T)[g + k]) / a->dt;            /* spcpl.py:518 */
             double f_SH = a->factor * ((qt_i - ql_i) - D(a->SH)[g + k]) / a->dt; /* spcpl.py:519 */
@@ -224,6 +308,9 @@ int oracle_backward_f64(const spc_dims *d, const spc_backward_args *a)
     }
     free(Zf);
     free(qlw);
+    free(tmp);
+    free(Zh);
+    free(Q);
     return SPC_OK;
 }
 

@@ -59,9 +59,16 @@ def forward(gcm, zf, zh, prof, factor, dt, couple_surface=True):
     return out
 
 
-def backward(gcm, Zf, zf, prof, factor, dt):
+def backward(gcm, Zf, zf, prof, factor, dt, conservative=False, zh=None, Zh=None):
     n, nG = gcm["T"].shape
     a = _abi.BackwardArgs()
+    if conservative:
+        a.conservative = 1
+        a.zh, a.rhobf_d = _p(zh), _p(prof["Rhobf"])
+        if Zh is not None:
+            a.Zh = _p(Zh)
+        else:
+            a.Zghalf = _p(gcm["Zghalf"])
     for k in ("T", "SH", "QL", "QI", "U", "V", "A"):
         setattr(a, k, _p(gcm[k]))
     if Zf is not None:

@@ -7,8 +7,10 @@ from oracle import spcpl_oracle as orc
 
 
 class RefCoupler:
-    def __init__(self, gcm, les_models, cplsurf=False, les_forcing_factor=1.0, gcm_forcing_factor=1.0):
+    def __init__(self, gcm, les_models, cplsurf=False, les_forcing_factor=1.0, gcm_forcing_factor=1.0,
+                 conservative=False):
         self.gcm, self.les_models = gcm, list(les_models)
+        self.conservative = conservative
         self.cplsurf, self.lf, self.gf = cplsurf, les_forcing_factor, gcm_forcing_factor
         self.firststep = True
         self.profiles = {}
@@ -62,7 +64,8 @@ class RefCoupler:
         for i, les in enumerate(self.les_models):                                             # splib.py:330-332
             col = {k: v[i] for k, v in data.items()}
             Zf, Zh = heights[les]
-            b = orc.set_gcm_tendencies(col, Zf, Zh, les.zf_cache, les.zh_cache, self.profiles[les], dt, self.gf)
+            b = orc.set_gcm_tendencies(col, Zf, Zh, les.zf_cache, les.zh_cache, self.profiles[les], dt, self.gf,
+                                       conservative=self.conservative)
             for var, key in (("U", "f_U"), ("V", "f_V"), ("T", "f_T"), ("SH", "f_SH"), ("QL", "f_QL"), ("QI", "f_QI"),
                              ("A", "f_A")):
                 gcm.set_profile_tendency(var, les.grid_index, b[key])

@@ -145,3 +145,17 @@ def test_synthetic_batch_is_physical_and_deterministic():
     assert zf[0] == 12.5 and zf[-1] == 3987.5 and zh[0] == 0.0 and zh[1] == 25.0   # dales-input/prof.inp.001
     A19, B19 = synthetic.hybrid_coefficients(19)
     assert A19[1] == 2000 and B19[-1] == 1 and len(A19) == 20
+
+
+@pytest.mark.parametrize("nG,nL", [(19, 160), (91, 160), (137, 512)])
+def test_conservative_c_oracle_bit_exact_vs_numpy_oracle(nG, nL):
+    """sputils.interp_c / integral incl. numpy's pairwise `.sum()` order, restated in C"""
+    gcm, zf, zh, prof = synthetic.make_batch(12, nG, nL, seed=300 + nG)
+    f = orc.forward_batched(gcm, prof, zf, zh)
+    ref = orc.backward_batched(gcm, f["Zf"], prof, zf, 0.9, 900.0, conservative=True, Zh=f["Zh"], zh=zh)
+    got = oracle_c.backward(gcm, f["Zf"], zf, prof, 0.9, 900.0, conservative=True, zh=zh, Zh=f["Zh"])
+    lin = orc.backward_batched(gcm, f["Zf"], prof, zf, 0.9, 900.0)
+    for k in ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A"):
+        assert numpy.array_equal(ref[k], got[k]), k
+    assert not numpy.array_equal(ref["f_T"], lin["f_T"])            # it really is a different scheme
+    assert numpy.array_equal(ref["f_A"], lin["f_A"])                # A is not interpolated

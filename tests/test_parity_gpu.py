@@ -239,3 +239,24 @@ def test_layout_and_argument_errors(eng):
     out = eng.forward(e, zf_d, pe, 1.0, DT)
     assert out["f_u"].shape == (0, 160)
 
+
+@pytest.mark.parametrize("n,nG,nL,per_col", [(40, 91, 160, False), (9, 19, 160, False), (64, 137, 512, False),
+                                             (33, 91, 160, True), (2500, 91, 160, False)])
+def test_conservative_coarsening_bit_exact(eng, n, nG, nL, per_col):
+    """K4 (sputils.interp_c / integral, flag conservative_coarsening) against the NumPy oracle, which
+    evaluates the reference's expressions with ndarray.sum(): bit-exact incl. the pairwise sum order."""
+    gcm, zf, zh, prof = synthetic.make_batch(n, nG, nL, seed=900 + n, per_column_grid=per_col)
+    g, p = to_dev(gcm, eng.device), to_dev(prof, eng.device)
+    zf_d, zh_d = torch.from_numpy(zf).to(eng.device), torch.from_numpy(zh).to(eng.device)
+    fwd = eng.forward(g, zf_d, p, FACTOR, DT, zh=zh_d)
+    got = eng.backward(g, zf_d, p, FACTOR, DT, Zf=fwd["Zf"], conservative=True, zh=zh_d, Zh=fwd["Zh"])
+    got2 = eng.backward(g, zf_d, p, FACTOR, DT, Zf=None, conservative=True, zh=zh_d)     # heights recomputed in-kernel
+    torch.cuda.synchronize()
+    ref_f = oracle_c.forward(gcm, zf, zh, prof, FACTOR, DT)
+    if n <= 64:
+        ref = orc.backward_batched(gcm, ref_f["Zf"], prof, zf, FACTOR, DT, conservative=True, Zh=ref_f["Zh"], zh=zh)
+    else:
+        ref = oracle_c.backward(gcm, ref_f["Zf"], zf, prof, FACTOR, DT, conservative=True, zh=zh, Zh=ref_f["Zh"])
+    check_backward({k: host(v) for k, v in got.items()}, ref)
+    check_backward({k: host(v) for k, v in got2.items()}, ref)
+    assert (host(got["f_T"]) != 0).any()

@@ -144,3 +144,17 @@ def test_gather_quirk_and_output_columns():
     for k in ("Tv", "Zh", "Zf", "Psurf", "Ph", "QT"):
         assert numpy.array_equal(D[k][1], one[k]), k
     assert numpy.abs(D["THL"][1] - one["THL"]).max() <= 8 * EPS * numpy.abs(one["THL"]).max()
+
+
+def test_conservative_coarsening_through_the_driver():
+    from sp_coupler_amd.driver import Coupler
+    gcm_a, les_a = models.make_models(6, nG=91, nL=160, seed=33)
+    gcm_b, les_b = models.make_models(6, nG=91, nL=160, seed=33)
+    cpl = Coupler(gcm_a, les_a, conservative_coarsening=True)
+    ref = RefCoupler(gcm_b, les_b, conservative=True)
+    for _ in range(2):
+        cpl.step()
+        ref.step()
+    for var in ("U", "V", "T", "SH", "QL", "QI", "A"):
+        a, b = gcm_a.state[var], gcm_b.state[var]
+        assert numpy.abs(a - b).max() <= 1e-11 * max(numpy.abs(b).max(), 1e-30), var

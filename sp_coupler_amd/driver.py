@@ -53,6 +53,8 @@ class Coupler:
         delta_t = gcm.get_timestep()
         starttime = time.time()
         w1 = -time.time()
+        if self.write and spcpl.writer is not None:                           # spio.update_time, splib.py:287-288
+            spcpl.writer.update_time(t + self.les_spinup + delta_t)
         if gcm.first_half_step_done:
             gcm.first_half_step_done = False
         else:

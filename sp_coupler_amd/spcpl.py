@@ -49,6 +49,7 @@ output_units = {"f_u": "m/s**2", "f_v": "m/s**2", "f_thl": "K/s", "f_qt": "mfu/s
 _engine = None
 _unit_wrapper = None
 writer = None      # optional spifs writer (sp_coupler_amd.spio.SpifsWriter); None = no output
+writer_rows = {}   # GCM grid index -> column index in the writer's file, for the extra output columns
 
 
 def get_engine():
@@ -193,7 +194,9 @@ def gather_gcm_data(gcm, les_models, couple_surface, output_column_indices=None,
         for v in surface_data:
             C[v] = surface_data[v][n0:]
         D = output_column_conversion(C)
-        writer.write_columns(extra_cols, D)
+        rows = [writer_rows[c] for c in extra_cols]      # column index of each extra output column in the file
+        writer.write(rows=rows, **{k: D[k] for k in ("U", "V", "T", "SH", "QL", "QI", "Pf", "Ph", "Zf", "Zh", "Psurf",
+                                                      "Tv", "THL", "QT", "A")})
     _current = batch
     return batch
 
@@ -246,7 +249,24 @@ def _ensure_forward(batch, les, firststep, profile, dt_gcm, factor, couple_surfa
     batch.fwd = forward_batched(batch, prof, dt_gcm, factor, couple_surface)
     batch.fwd["rain"] = prof["Rain"].cpu().numpy()
     batch.fwd_key = key
+    batch.fwd_written = False
     return batch.fwd
+
+
+def _write_forward(batch):
+    """spifs rows of convert_profiles + set_les_forcings for ALL columns (spcpl.py:230-244, 352-376)."""
+    f, g = batch.fwd, batch.gcm_host
+    n = batch.n
+    d = {k: v.cpu().numpy() for k, v in batch.engine.diagnostics(batch.gcm).items()}     # K5: Tv, THL, QT
+    writer.write(U=g["U"][:n], V=g["V"][:n], T=g["T"][:n], SH=g["SH"][:n], QL=g["QL"][:n], QI=g["QI"][:n],
+                 Pf=g["Pfull"][:n], Ph=g["Phalf"][:n, 1:], Zf=f["Zf"], Zh=f["Zh"][:, 1:], Psurf=g["Phalf"][:n, -1],
+                 Tv=d["Tv"], THL=d["THL"], QT=d["QT"], f_u=f["f_u"], f_v=f["f_v"], f_thl=f["f_thl"], f_qt=f["f_qt"],
+                 rain=f["rain"], rainrate=f["rainrate"] * 3600)                              # spcpl.py:358
+    if "wthl" in f:
+        s = batch.surf_host
+        writer.write(z0m=f["z0m"], z0h=f["z0h"], wthl=f["wthl"], wqt=f["wqt"], TLflux=s["TLflux"][:n],
+                     TSflux=s["TSflux"][:n], SHflux=s["SHflux"][:n], QLflux=s["QLflux"][:n], QIflux=s["QIflux"][:n])
+    batch.fwd_written = True
 
 
 def convert_profiles(les, write=True):
@@ -263,8 +283,6 @@ def convert_profiles(les, write=True):
     c = batch.conv
     les.gcm_Zf = _wrap("Zf", c["Zf"][i])                                     # spcpl.py:200
     les.gcm_Zh = _wrap("Zh", c["Zh"][i])                                     # spcpl.py:201
-    if write and writer is not None:
-        writer.write_les_gcm_state(les, batch, i)
     return (_wrap("u", c["u"][i]), _wrap("v", c["v"][i]), _wrap("thl", c["thl"][i]), _wrap("qt", c["qt"][i]),
             _wrap("ps", c["ps"][i]), _wrap("ql", c["ql_ref"][i]))
 
@@ -290,8 +308,8 @@ def set_les_forcings(les, gcm, asynchronous, firststep, profile, dt_gcm, factor,
         "QLp": les.set_ref_profile_QL(_wrap("ql_ref", f["ql_ref"][i]), return_request=asynchronous),     # :347
     }
     les.ql_ref = _wrap("ql_ref", f["ql_ref"][i])                             # spcpl.py:348
-    if write and writer is not None:
-        writer.write_les_forcings(les, f, i)
+    if write and writer is not None and not batch.fwd_written:
+        _write_forward(batch)                    # once per launch, for all columns
     if couple_surface:                                                       # spcpl.py:359-364
         req["Z0M_surf"] = les.set_z0m_surf(_wrap("z0m", f["z0m"][i]), return_request=asynchronous)
         req["Z0H_surf"] = les.set_z0h_surf(_wrap("z0h", f["z0h"][i]), return_request=asynchronous)
@@ -404,6 +422,8 @@ def set_gcm_tendencies(gcm, les, profile, dt_gcm, factor=1, write=True, conserva
         prof = batch.stack_profiles(keys, lambda m: batch.profiles[id(m)])
         batch.bwd = backward_batched(batch, prof, dt_gcm, factor, conservative)
         batch.bwd_key = key
+        if write and writer is not None:
+            _write_backward(batch, prof)         # once per launch, for all columns
     b = batch.bwd
     i = batch.index_of(les)
     gcm.set_profile_tendency("U", les.grid_index, _wrap("f_U", b["f_U"][i]))     # spcpl.py:535
@@ -413,8 +433,21 @@ def set_gcm_tendencies(gcm, les, profile, dt_gcm, factor=1, write=True, conserva
     gcm.set_profile_tendency("QL", les.grid_index, _wrap("f_QL", b["f_QL"][i]))
     gcm.set_profile_tendency("QI", les.grid_index, _wrap("f_QI", b["f_QI"][i]))
     gcm.set_profile_tendency("A", les.grid_index, _wrap("f_A", b["f_A"][i]))     # spcpl.py:542
-    if write and writer is not None:
-        writer.write_les_tendencies(les, batch, b, i)
+
+
+def _write_backward(batch, prof):
+    """spifs rows of set_gcm_tendencies for ALL columns (spcpl.py:412-425, 545-555)."""
+    b, n = batch.bwd, batch.n
+    src = lambda m: batch.profiles[id(m)]        # noqa: E731
+    extra = batch.stack_profiles(("THL", "presf", "Rhof", "Rhobf", "QR"), src)
+    dprof = dict(prof, THL=extra["THL"])
+    d = batch.engine.diagnostics(batch.gcm, batch.zf, dprof)                                 # K5: t, ql_water
+    h = lambda t: t.cpu().numpy()                # noqa: E731
+    writer.write(u=h(prof["U"]), v=h(prof["V"]), presf=h(extra["presf"]), rhof=h(extra["Rhof"]),
+                 rhobf=h(extra["Rhobf"]), qt=h(prof["QT"]), ql=h(prof["QL"]), ql_ice=h(prof["QL_ice"]),
+                 ql_water=h(d["ql_water"]), thl=h(extra["THL"]), t=h(d["t"]), t_=h(prof["T"]), qr=h(extra["QR"]),
+                 f_U=b["f_U"], f_V=b["f_V"], f_T=b["f_T"], f_SH=b["f_SH"], f_QL=b["f_QL"], f_QI=b["f_QI"], f_A=b["f_A"],
+                 A=batch.gcm_host["A"][:n], A_d=h(prof["A"])[:, ::-1])                       # spcpl.py:404,550-551
 
 
 def set_gcm_tendencies_batched(gcm, les_models, profiles, dt_gcm, factor=1, write=True, conservative=False):

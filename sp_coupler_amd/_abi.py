@@ -79,6 +79,7 @@ PROTOTYPES = {
     "spc_device_count": (ctypes.c_int, []),
     "spc_pick_cols_per_block": (ctypes.c_int, [ctypes.POINTER(Dims), ctypes.c_int]),
     "spc_stream_copy": (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "spc_stream_copy_f64": (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
 }
 
 _lib = None

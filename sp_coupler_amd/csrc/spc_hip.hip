@@ -705,6 +705,13 @@ __global__ __launch_bounds__(BLOCK) void k_copy16(uint4 *dst, const uint4 *src, 
         dst[i] = src[i];
 }
 
+// 8 B/lane streaming copy: the access width of the coupling kernels (PMC calibration, tools/pmc_summary.py)
+__global__ __launch_bounds__(BLOCK) void k_copy8(double *dst, const double *src, int64_t n8)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n8; i += (int64_t)gridDim.x * BLOCK)
+        dst[i] = src[i];
+}
+
 // ---- host side --------------------------------------------------------------------------------
 int floor_pow2(int n)
 {
@@ -1007,6 +1014,14 @@ int spc_stream_copy(void *dst, const void *src, int64_t bytes, void *stream)
     if (bytes == 0) return SPC_OK;
     hipLaunchKernelGGL(k_copy16, dim3(2048), dim3(BLOCK), 0, (hipStream_t)stream, (uint4 *)dst, (const uint4 *)src, bytes / 16);
     return launch_status("k_copy16");
+}
+
+int spc_stream_copy_f64(void *dst, const void *src, int64_t bytes, void *stream)
+{
+    if (bytes < 0 || (bytes & 7) || !dst || !src) return fail(SPC_ERR_INVALID_ARGUMENT, "%sstream_copy_f64: bytes must be a multiple of 8, pointers non-NULL");
+    if (bytes == 0) return SPC_OK;
+    hipLaunchKernelGGL(k_copy8, dim3(2048), dim3(BLOCK), 0, (hipStream_t)stream, (double *)dst, (const double *)src, bytes / 8);
+    return launch_status("k_copy8");
 }
 
 }  // extern "C"

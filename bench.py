@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--cols-per-block", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP-event pass")
+    ap.add_argument("--backend", default="nccl", help="process-group backend for N>1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--device", type=int, default=None, help="force this HIP device for every rank (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
 
     import numpy
@@ -78,11 +80,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    if args.device is not None:
+        local = args.device
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
 
     n_cols, nG, nL, seed = synthetic.CONFIGS[args.config]
     if args.cols:
@@ -129,7 +136,7 @@ def main():
     elapsed = time.perf_counter() - t0
     fence()
     if dist is not None:
-        tt = torch.tensor([elapsed], device=eng.device, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=eng.device if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

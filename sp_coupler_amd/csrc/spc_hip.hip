@@ -31,7 +31,10 @@
 
 namespace {
 
-constexpr int BLOCK = 256;
+#ifndef SPC_BLOCK
+#define SPC_BLOCK 256
+#endif
+constexpr int BLOCK = SPC_BLOCK;
 constexpr int MAX_LDS_BYTES = 64 * 1024;  // default dynamic-LDS limit; keeps >= 2 workgroups per CU
 
 thread_local char g_err[512] = "";
@@ -48,8 +51,40 @@ template <typename T> struct K {
                        grav = T(9.81);
 };
 
+#if SPC_FASTPOW
+__device__ __forceinline__ double spc_pow(double x, double y) { return exp(y * log(x)); }
+__device__ __forceinline__ float spc_pow(float x, float y) { return expf(y * logf(x)); }
+#else
 __device__ __forceinline__ double spc_pow(double x, double y) { return pow(x, y); }
 __device__ __forceinline__ float spc_pow(float x, float y) { return powf(x, y); }
+#endif
+
+// Streaming accesses of the hot kernels: every input element is read once and every output written
+// once per launch.  -DSPC_NT=1 marks them non-temporal (experiment switch).
+#ifndef SPC_NT
+#define SPC_NT 0
+#endif
+template <typename T> __device__ __forceinline__ T ldg(const T *q)
+{
+#if SPC_NT
+    return __builtin_nontemporal_load(q);
+#else
+    return *q;
+#endif
+}
+template <typename T> __device__ __forceinline__ void stg(T *q, T v)
+{
+#if SPC_NT
+    __builtin_nontemporal_store(v, q);
+#else
+    *q = v;
+#endif
+}
+
+// -DSPC_FASTPOW=1: x**y as exp(y*log(x)) (|y log x| < 2 on this path, ~4 ulp) instead of ocml pow (<1 ulp)
+#ifndef SPC_FASTPOW
+#define SPC_FASTPOW 0
+#endif
 
 // Every quotient on this path is a true IEEE division (x / y), never x * (1/y): the reference divides,
 // and bit-parity of the u/v/qt/ql forcings and of all tendencies depends on it.  (Tried and measured
@@ -216,15 +251,23 @@ template <typename P, typename T = decltype(+*P().zf)>
 __device__ __forceinline__ LesIn<T> load_les(const P &p, int l, int64_t o)
 {
     LesIn<T> r;
-    r.h = p.d.shared_grid ? p.zf[l] : p.zf[o];                                        // spcpl.py:222
-    r.ud = p.u_d[o]; r.vd = p.v_d[o]; r.thld = p.thl_d[o]; r.qtd = p.qt_d[o]; r.qld = p.ql_d[o];
+    r.h = p.d.shared_grid ? ldg(&p.zf[l]) : ldg(&p.zf[o]);                                        // spcpl.py:222
+    r.ud = ldg(&p.u_d[o]); r.vd = ldg(&p.v_d[o]); r.thld = ldg(&p.thl_d[o]); r.qtd = ldg(&p.qt_d[o]); r.qld = ldg(&p.ql_d[o]);
     return r;
 }
 
-template <typename T, bool FULL> __global__ __launch_bounds__(BLOCK) void k_forward(const FwdP<T, FULL> p)
+constexpr int cfloor_pow2(int n) { int p = 1; while (p * 2 <= n) p *= 2; return p; }
+
+// NG / NL != 0: level counts fixed at compile time and contiguous columns (pitch == level count): the
+// flat-index divisions become multiply-shifts, the searches unroll, no pitch registers (hot geometries
+// 91<->160, 137<->512, 19<->160); NG == NL == 0: everything from DimsP at run time.
+template <typename T, bool FULL, int NG, int NL>
+__global__ __launch_bounds__(BLOCK) void k_forward(const FwdP<T, FULL> p)
 {
     const DimsP &d = p.d;
-    const int nG = d.nG, nL = d.nL, cb = d.cb;
+    const int nG = NG ? NG : d.nG, nL = NL ? NL : d.nL, cb = d.cb;
+    const int64_t pitchG = NG ? NG : d.pitchG, pitchGh = NG ? NG + 1 : d.pitchGh, pitchL = NL ? NL : d.pitchL;
+    const int p2G = NG ? cfloor_pow2(NG ? NG : 1) : d.p2G;
     const int tid = threadIdx.x;
     const int64_t col0 = (int64_t)blockIdx.x * cb;
     const int ncol = (int)((d.n_cols - col0) < cb ? (d.n_cols - col0) : cb);
@@ -240,18 +283,18 @@ template <typename T, bool FULL> __global__ __launch_bounds__(BLOCK) void k_forw
     T pre_zgh = T(0), pre_zs = T(0);
     if (tid < n2) {
         const int c = tid / nL, l = tid - c * nL;
-        pre2 = load_les<FwdP<T, FULL>, T>(p, l, (col0 + c) * d.pitchL + l);
+        pre2 = load_les<FwdP<T, FULL>, T>(p, l, (col0 + c) * pitchL + l);
     } else if (tid < nitems) {
         const int ei = tid - n2, c = ei / nG, m = ei - c * nG;
-        const int64_t gh = (col0 + c) * d.pitchGh;
-        pre_zgh = p.Zghalf[gh + (nG - 1 - m)];
-        pre_zs = p.Zghalf[gh + nG];
+        const int64_t gh = (col0 + c) * pitchGh;
+        pre_zgh = ldg(&p.Zghalf[gh + (nG - 1 - m)]);
+        pre_zs = ldg(&p.Zghalf[gh + nG]);
     }
     const int sc = BLOCK - 1 - tid;          // the LAST threads own the per-column scalars
     T sc_ps = T(0), sc_psd = T(0), sc_rain = T(0), sc_rl = T(0);
     if (sc < ncol) {
-        sc_ps = p.Ph[(col0 + sc) * d.pitchGh + nG];                                   // spcpl.py:246
-        sc_psd = p.ps_d[col0 + sc];
+        sc_ps = ldg(&p.Ph[(col0 + sc) * pitchGh + nG]);                                   // spcpl.py:246
+        sc_psd = ldg(&p.ps_d[col0 + sc]);
         if constexpr (FULL)
             if (p.o.rainrate) { sc_rain = p.o.rain[col0 + sc]; sc_rl = p.o.rain_last[col0 + sc]; }
     }
@@ -259,7 +302,7 @@ template <typename T, bool FULL> __global__ __launch_bounds__(BLOCK) void k_forw
         const int nz = d.shared_grid ? nL : n2;
         for (int e = tid; e < nz; e += BLOCK) {
             const int c = e / nL, l = e - c * nL;
-            lzh[e] = d.shared_grid ? p.zh[e] : p.zh[(col0 + c) * d.pitchL + l];
+            lzh[e] = d.shared_grid ? p.zh[e] : p.zh[(col0 + c) * pitchL + l];
         }
     }
     STAMP(1);
@@ -267,10 +310,10 @@ template <typename T, bool FULL> __global__ __launch_bounds__(BLOCK) void k_forw
     // ---- phase 1: load GCM levels (flat over the [ncol x nG] slab), convert, stage reversed ----
     for (int e = tid; e < n1; e += BLOCK) {
         const int c = e / nG, k = e - c * nG;
-        const int64_t col = col0 + c, g = col * d.pitchG + k;
-        const T zsurf = p.Zghalf[col * d.pitchGh + nG];
-        const T tt = p.Tm[g], sh = p.SH[g], ql = p.QL[g], qi = p.QI[g], pf = p.Pf[g], zg = p.Zgfull[g];
-        const T uu = p.U[g], vv = p.V[g];
+        const int64_t col = col0 + c, g = col * pitchG + k;
+        const T zsurf = ldg(&p.Zghalf[col * pitchGh + nG]);
+        const T tt = ldg(&p.Tm[g]), sh = ldg(&p.SH[g]), ql = ldg(&p.QL[g]), qi = ldg(&p.QI[g]), pf = ldg(&p.Pf[g]), zg = ldg(&p.Zgfull[g]);
+        const T uu = ldg(&p.U[g]), vv = ldg(&p.V[g]);
         const T zf_k = div_grav(zg - zsurf);                                          // spcpl.py:198
         T *const s = lds + (size_t)c * 6 * nG + (nG - 1 - k);                         // [::-1], spcpl.py:224
         s[0] = zf_k;
@@ -290,12 +333,12 @@ template <typename T, bool FULL> __global__ __launch_bounds__(BLOCK) void k_forw
     // ---- per-column scalars (inputs already in registers; stores drain behind phase 2) ----------
     if (sc < ncol) {
         const int64_t col = col0 + sc;
-        p.f_ps[col] = p.factor * (sc_ps - sc_psd) / p.dt;          // spcpl.py:332
+        stg(&p.f_ps[col], p.factor * (sc_ps - sc_psd) / p.dt);          // spcpl.py:332
         if constexpr (FULL) {
             if (p.o.ps) p.o.ps[col] = sc_ps;
             if (p.o.rainrate) p.o.rainrate[col] = (sc_rain - sc_rl) / p.dt;   // spcpl.py:325
             if (p.o.wthl) {                                                            // spcpl.py:136-167
-                const T rho = sc_ps / (K<T>::rd * p.Tm[col * d.pitchG + nG - 1]);      // spcpl.py:153
+                const T rho = sc_ps / (K<T>::rd * ldg(&p.Tm[col * pitchG + nG - 1]));      // spcpl.py:153
                 p.o.wqt[col] = -(p.o.QLflux[col] + p.o.QIflux[col] + p.o.SHflux[col]) / rho;     // spcpl.py:159
                 p.o.wthl[col] = -p.o.TSflux[col] * spc_pow(div_pref0(sc_ps), (-K<T>::rd) / K<T>::cp)
                                 / (K<T>::cp * rho);                                    // spcpl.py:161
@@ -309,21 +352,21 @@ template <typename T, bool FULL> __global__ __launch_bounds__(BLOCK) void k_forw
     for (int e = tid; e < nitems; e += BLOCK) {
         if (e < n2) {
             const int c = e / nL, l = e - c * nL;
-            const int64_t col = col0 + c, o = col * d.pitchL + l;
+            const int64_t col = col0 + c, o = col * pitchL + l;
             const T *const s = lds + (size_t)c * 6 * nG;
             const LesIn<T> in = (e == tid) ? pre2 : load_les<FwdP<T, FULL>, T>(p, l, o);
-            const Bracket<T> b = bracket(s, nG, d.p2G, in.h);
+            const Bracket<T> b = bracket(s, nG, p2G, in.h);
             const T thl = interp_at(b, s + nG);                                       // spcpl.py:224
             const T qt = interp_at(b, s + 2 * nG);                                    // spcpl.py:225
             const T ql = interp_at(b, s + 3 * nG);                                    // spcpl.py:226
             const T u = interp_at(b, s + 4 * nG);                                     // spcpl.py:227
             const T v = interp_at(b, s + 5 * nG);                                     // spcpl.py:228
-            p.f_u[o] = p.factor * (u - in.ud) / p.dt;               // spcpl.py:328
-            p.f_v[o] = p.factor * (v - in.vd) / p.dt;               // spcpl.py:329
-            p.f_thl[o] = p.factor * (thl - in.thld) / p.dt;         // spcpl.py:330
-            p.f_qt[o] = p.factor * (qt - in.qtd) / p.dt;            // spcpl.py:331
-            p.f_ql[o] = p.factor * (ql - in.qld) / p.dt;            // spcpl.py:333
-            p.ql_ref[o] = ql;                                                         // spcpl.py:347-348
+            stg(&p.f_u[o], p.factor * (u - in.ud) / p.dt);               // spcpl.py:328
+            stg(&p.f_v[o], p.factor * (v - in.vd) / p.dt);               // spcpl.py:329
+            stg(&p.f_thl[o], p.factor * (thl - in.thld) / p.dt);         // spcpl.py:330
+            stg(&p.f_qt[o], p.factor * (qt - in.qtd) / p.dt);            // spcpl.py:331
+            stg(&p.f_ql[o], p.factor * (ql - in.qld) / p.dt);            // spcpl.py:333
+            stg(&p.ql_ref[o], ql);                                                         // spcpl.py:347-348
             if constexpr (FULL) {
                 if (p.o.u) p.o.u[o] = u;
                 if (p.o.v) p.o.v[o] = v;
@@ -332,12 +375,12 @@ template <typename T, bool FULL> __global__ __launch_bounds__(BLOCK) void k_forw
             }
         } else {                                                                      // fused K2, spcpl.py:764
             const int ei = e - n2, c = ei / nG, m = ei - c * nG;
-            const int64_t col = col0 + c, gh = col * d.pitchGh;
-            const T zgh = (e == tid) ? pre_zgh : p.Zghalf[gh + (nG - 1 - m)];
-            const T zs = (e == tid) ? pre_zs : p.Zghalf[gh + nG];
+            const int64_t col = col0 + c, gh = col * pitchGh;
+            const T zgh = (e == tid) ? pre_zgh : ldg(&p.Zghalf[gh + (nG - 1 - m)]);
+            const T zs = (e == tid) ? pre_zs : ldg(&p.Zghalf[gh + nG]);
             const T Zh_k = div_grav(zgh - zs);                                        // spcpl.py:197
             const T *const zh = d.shared_grid ? lzh : lzh + (size_t)c * nL;
-            p.idx[col * d.pitchG + m] = ss_right(zh, nL, Zh_k);
+            p.idx[col * pitchG + m] = ss_right(zh, nL, Zh_k);
         }
     }
     STAMP(4);
@@ -347,8 +390,8 @@ template <typename T, bool FULL> __global__ __launch_bounds__(BLOCK) void k_forw
         if (p.o.Zh) {
             for (int e = tid; e < ncol * (nG + 1); e += BLOCK) {
                 const int c = e / (nG + 1), k = e - c * (nG + 1);
-                const int64_t gh = (col0 + c) * d.pitchGh;
-                p.o.Zh[gh + k] = div_grav(p.Zghalf[gh + k] - p.Zghalf[gh + nG]);
+                const int64_t gh = (col0 + c) * pitchGh;
+                p.o.Zh[gh + k] = div_grav(ldg(&p.Zghalf[gh + k]) - ldg(&p.Zghalf[gh + nG]));
             }
         }
     }
@@ -391,15 +434,17 @@ template <typename T> struct GcmIn {
 template <typename T> __device__ __forceinline__ GcmIn<T> load_gcm(const BwdP<T> &p, int64_t g, int64_t g_rev)
 {
     GcmIn<T> r;
-    r.tt = p.Tm[g]; r.sh = p.SH[g]; r.ql = p.QL[g]; r.qi = p.QI[g]; r.u = p.U[g]; r.v = p.V[g]; r.a = p.A[g];
-    r.a_d = p.A_prof[g_rev];                                                           // spcpl.py:404
+    r.tt = ldg(&p.Tm[g]); r.sh = ldg(&p.SH[g]); r.ql = ldg(&p.QL[g]); r.qi = ldg(&p.QI[g]); r.u = ldg(&p.U[g]); r.v = ldg(&p.V[g]); r.a = ldg(&p.A[g]);
+    r.a_d = ldg(&p.A_prof[g_rev]);                                                           // spcpl.py:404
     return r;
 }
 
-template <typename T> __global__ __launch_bounds__(BLOCK) void k_backward(const BwdP<T> p)
+template <typename T, int NG, int NL> __global__ __launch_bounds__(BLOCK) void k_backward(const BwdP<T> p)
 {
     const DimsP &d = p.d;
-    const int nG = d.nG, nL = d.nL, cb = d.cb, tid = threadIdx.x;
+    const int nG = NG ? NG : d.nG, nL = NL ? NL : d.nL, cb = d.cb, tid = threadIdx.x;
+    const int64_t pitchG = NG ? NG : d.pitchG, pitchGh = NG ? NG + 1 : d.pitchGh, pitchL = NL ? NL : d.pitchL;
+    const int p2L = NL ? cfloor_pow2(NL ? NL : 1) : d.p2L;
     const int64_t col0 = (int64_t)blockIdx.x * cb;
     const int ncol = (int)((d.n_cols - col0) < cb ? (d.n_cols - col0) : cb);
     const size_t per_col = (size_t)6 * nL + nG;
@@ -411,43 +456,43 @@ template <typename T> __global__ __launch_bounds__(BLOCK) void k_backward(const 
     GcmIn<T> pre = {};
     if (tid < n1) {
         const int c = tid / nG, k = tid - c * nG;
-        const int64_t cg = (col0 + c) * d.pitchG;
+        const int64_t cg = (col0 + c) * pitchG;
         pre = load_gcm(p, cg + k, cg + (nG - 1 - k));
     }
 
     for (int e = tid; e < ncol * nL; e += BLOCK) {
         const int c = e / nL, l = e - c * nL;
-        const int64_t o = (col0 + c) * d.pitchL + l;
+        const int64_t o = (col0 + c) * pitchL + l;
         T *const s = lds + (size_t)c * per_col + l;
-        s[0] = p.t_d[o];
-        s[nL] = p.qt_d[o];
-        s[2 * nL] = p.ql_d[o];
-        s[3 * nL] = p.ql_ice_d[o];
-        s[4 * nL] = p.u_d[o];
-        s[5 * nL] = p.v_d[o];
-        if (!d.shared_grid) lh[e] = p.zf[o];
+        s[0] = ldg(&p.t_d[o]);
+        s[nL] = ldg(&p.qt_d[o]);
+        s[2 * nL] = ldg(&p.ql_d[o]);
+        s[3 * nL] = ldg(&p.ql_ice_d[o]);
+        s[4 * nL] = ldg(&p.u_d[o]);
+        s[5 * nL] = ldg(&p.v_d[o]);
+        if (!d.shared_grid) lh[e] = ldg(&p.zf[o]);
     }
     if (d.shared_grid)
-        for (int e = tid; e < nL; e += BLOCK) lh[e] = p.zf[e];
+        for (int e = tid; e < nL; e += BLOCK) lh[e] = ldg(&p.zf[e]);
     for (int e = tid; e < n1; e += BLOCK) {
         const int c = e / nG, k = e - c * nG;
-        const int64_t col = col0 + c, g = col * d.pitchG + k;
+        const int64_t col = col0 + c, g = col * pitchG + k;
         const T zf_k = p.Zf ? p.Zf[g]
-                            : div_grav(p.Zgfull[g] - p.Zghalf[col * d.pitchGh + nG]);       // spcpl.py:198
+                            : div_grav(ldg(&p.Zgfull[g]) - ldg(&p.Zghalf[col * pitchGh + nG]));       // spcpl.py:198
         lds[(size_t)c * per_col + 6 * nL + k] = zf_k;
     }
     __syncthreads();
 
     for (int e = tid; e < n1; e += BLOCK) {
         const int c = e / nG, k = e - c * nG;
-        const int64_t col = col0 + c, cg = col * d.pitchG, g = cg + k;
+        const int64_t col = col0 + c, cg = col * pitchG, g = cg + k;
         const T *const s = lds + (size_t)c * per_col;
         const T *const h = d.shared_grid ? lh : lh + (size_t)c * nL;
         const T *const Zf = s + 6 * nL;
         const GcmIn<T> in = (e == tid) ? pre : load_gcm(p, g, cg + (nG - 1 - k));
         const T x = Zf[k];
         const int start_index = ss_left_neg(Zf, nG, h[nL - 1]);                        // spcpl.py:498
-        const Bracket<T> b = bracket(h, nL, d.p2L, x);
+        const Bracket<T> b = bracket(h, nL, p2L, x);
         T t_i, qt_i, ql_i, qlw_i, qli_i, u_i, v_i;
         if (b.mode == 0) {
             const int j = b.j;
@@ -482,13 +527,13 @@ template <typename T> __global__ __launch_bounds__(BLOCK) void k_backward(const 
             const T zero = T(0);
             f_T *= zero; f_SH *= zero; f_QL *= zero; f_QI *= zero; f_U *= zero; f_V *= zero; f_A *= zero;
         }
-        p.f_T[g] = f_T;
-        p.f_SH[g] = f_SH;
-        p.f_QL[g] = f_QL;
-        p.f_QI[g] = f_QI;
-        p.f_U[g] = f_U;
-        p.f_V[g] = f_V;
-        p.f_A[g] = f_A;
+        stg(&p.f_T[g], f_T);
+        stg(&p.f_SH[g], f_SH);
+        stg(&p.f_QL[g], f_QL);
+        stg(&p.f_QI[g], f_QI);
+        stg(&p.f_U[g], f_U);
+        stg(&p.f_V[g], f_V);
+        stg(&p.f_A[g], f_A);
         if (p.start_index && k == 0) p.start_index[col] = start_index;
     }
 }
@@ -790,6 +835,16 @@ template <typename KernelT> int pick_cb(const spc_dims *d, int pass, bool with_i
     return best;
 }
 
+// 0 = generic; 1..3 = compile-time geometries with contiguous columns (see k_forward)
+int geometry_id(const spc_dims *d)
+{
+    if (d->pitchG != d->nG || d->pitchGh != d->nG + 1 || d->pitchL != d->nL) return 0;
+    if (d->nG == 91 && d->nL == 160) return 1;
+    if (d->nG == 137 && d->nL == 512) return 2;
+    if (d->nG == 19 && d->nL == 160) return 3;
+    return 0;
+}
+
 DimsP make_dims(const spc_dims *d, int cb)
 {
     DimsP p;
@@ -833,8 +888,14 @@ template <typename T> int forward_impl(const spc_dims *d, const spc_forward_args
     }
     const bool with_idx = a->idx != nullptr;
     const bool full = a->u || a->v || a->thl || a->qt || a->ps || a->Zf || a->Zh || a->rainrate || a->wthl;
-    const int cb = full ? pick_cb(d, 0, with_idx, sizeof(T), k_forward<T, true>)
-                        : pick_cb(d, 0, with_idx, sizeof(T), k_forward<T, false>);
+    const int geo = geometry_id(d);
+    using KFull = void (*)(const FwdP<T, true>);
+    using KLean = void (*)(const FwdP<T, false>);
+    static const KFull kfull[4] = {k_forward<T, true, 0, 0>, k_forward<T, true, 91, 160>, k_forward<T, true, 137, 512>,
+                                   k_forward<T, true, 19, 160>};
+    static const KLean klean[4] = {k_forward<T, false, 0, 0>, k_forward<T, false, 91, 160>, k_forward<T, false, 137, 512>,
+                                   k_forward<T, false, 19, 160>};
+    const int cb = full ? pick_cb(d, 0, with_idx, sizeof(T), kfull[geo]) : pick_cb(d, 0, with_idx, sizeof(T), klean[geo]);
     size_t per_col, fixed;
     lds_elems(d, 0, with_idx, &per_col, &fixed);
     const size_t smem = (per_col * cb + fixed) * sizeof(T);
@@ -857,11 +918,11 @@ template <typename T> int forward_impl(const spc_dims *d, const spc_forward_args
         fill(p);
         COP(rain); COP(rain_last); OOP(u); OOP(v); OOP(thl); OOP(qt); OOP(ps); OOP(Zf); OOP(Zh); OOP(rainrate);
         COP(Z0M); COP(Z0H); COP(QLflux); COP(QIflux); COP(SHflux); COP(TSflux); OOP(z0m); OOP(z0h); OOP(wthl); OOP(wqt);
-        hipLaunchKernelGGL((k_forward<T, true>), dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(kfull[geo], dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
     } else {
         FwdP<T, false> p;
         fill(p);
-        hipLaunchKernelGGL((k_forward<T, false>), dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(klean[geo], dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
     }
     return launch_status("k_forward");
 }
@@ -905,7 +966,10 @@ template <typename T> int backward_impl(const spc_dims *d, const spc_backward_ar
         if (d->nL < 2) return fail(SPC_ERR_INVALID_ARGUMENT, "%sconservative coarsening needs nL >= 2");
         if (d->nL > 513) return fail(SPC_ERR_UNSUPPORTED, "%sconservative coarsening supports nL <= 513 (pairwise-sum tree depth)");
     }
-    const int cb = cons ? pick_cb(d, 4, false, sizeof(T), k_backward_cons<T>) : pick_cb(d, 1, false, sizeof(T), k_backward<T>);
+    const int geo = geometry_id(d);
+    using KB = void (*)(const BwdP<T>);
+    static const KB kb[4] = {k_backward<T, 0, 0>, k_backward<T, 91, 160>, k_backward<T, 137, 512>, k_backward<T, 19, 160>};
+    const int cb = cons ? pick_cb(d, 4, false, sizeof(T), k_backward_cons<T>) : pick_cb(d, 1, false, sizeof(T), kb[geo]);
     size_t per_col, fixed;
     lds_elems(d, cons ? 4 : 1, false, &per_col, &fixed);
     const size_t smem = (per_col * cb + fixed) * sizeof(T);
@@ -921,7 +985,7 @@ template <typename T> int backward_impl(const spc_dims *d, const spc_backward_ar
     if (cons)
         hipLaunchKernelGGL(k_backward_cons<T>, dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL(k_backward<T>, dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(kb[geo], dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
     return launch_status(cons ? "k_backward_cons" : "k_backward");
 }
 
@@ -999,8 +1063,8 @@ int spc_pick_cols_per_block(const spc_dims *d, int pass)
     int rc = validate(d);
     if (rc) return rc;
     switch (pass) {
-    case 0: return pick_cb(d, 0, true, sizeof(double), k_forward<double, false>);
-    case 1: return pick_cb(d, 1, false, sizeof(double), k_backward<double>);
+    case 0: return pick_cb(d, 0, true, sizeof(double), k_forward<double, false, 0, 0>);
+    case 1: return pick_cb(d, 1, false, sizeof(double), k_backward<double, 0, 0>);
     case 2: return pick_cb(d, 2, true, sizeof(double), k_cloud_idx<double>);
     case 3: return pick_cb(d, 3, false, sizeof(double), k_diag<double>);
     case 4: return pick_cb(d, 4, false, sizeof(double), k_backward_cons<double>);

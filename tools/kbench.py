@@ -43,6 +43,7 @@ def main():
         data = []
         for r in range(rot):
             gcm, zf, zh, prof = synthetic.make_batch(n, nG, nL, seed=100 + r, couple_surface=False)
+            prof = {k: v for k, v in prof.items() if k not in ("Rain", "rain_last")}      # lean hot path, as bench.py
             g = {k: torch.from_numpy(v).to(eng.device, dtype) for k, v in gcm.items()}
             p = {k: torch.from_numpy(v).to(eng.device, dtype) for k, v in prof.items()}
             data.append((g, torch.from_numpy(zf).to(eng.device, dtype), torch.from_numpy(zh).to(eng.device, dtype), p))

@@ -1,0 +1,134 @@
+"""-m gpu: BASELINE.json's full-size configurations (4: T511, 348 528 columns 91<->160; 5: T255, 88 838 columns
+137<->512) on one GPU.  The NumPy oracle cannot cover these sizes in seconds, so the checks are
+(1) bit-parity against the plain-C oracle on a random sample of columns, and (2) size-independent
+properties on the WHOLE batch: batch-split invariance (columns are independent), exact linearity in the
+forcing factor (x2 is exact in binary fp), and index-range / masking invariants."""
+import numpy
+import pytest
+import torch
+
+from sp_coupler_amd import synthetic
+from tests import oracle_c
+from tests.gpu_util import EPS, assert_bits, host
+
+pytestmark = pytest.mark.gpu
+DT = 900.0
+
+
+def tiled_batch(n, nG, nL, seed, base=4096):
+    """n columns from a `base`-column synthetic batch, tiled with a per-tile perturbation (the generator
+    itself is too slow for 3.5e5 columns); heights are untouched, so they stay monotone."""
+    gcm, zf, zh, prof = synthetic.make_batch(base, nG, nL, seed=seed)
+    reps = -(-n // base)
+    tile = numpy.repeat(numpy.arange(reps, dtype=numpy.float64), base)[:n]
+
+    def rep(a):
+        return numpy.ascontiguousarray(numpy.concatenate([a] * reps, axis=0)[:n])
+    g = {k: rep(v) for k, v in gcm.items()}
+    p = {k: rep(v) for k, v in prof.items()}
+    g["T"] += 0.01 * tile[:, None]
+    g["U"] *= (1.0 + 1e-3 * tile[:, None])
+    p["THL"] += 0.02 * tile[:, None]
+    p["V"] -= 0.05 * tile[:, None]
+    p["PS"] += tile
+    return g, zf, zh, p
+
+
+def dev(d, device, dtype=torch.float64):
+    return {k: torch.from_numpy(v).to(device, dtype) for k, v in d.items()}
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from sp_coupler_amd.engine import Engine
+    return Engine("cuda:0")
+
+
+@pytest.mark.parametrize("cfg", [4, 5])
+def test_full_size_config(eng, cfg):
+    n, nG, nL, seed = synthetic.CONFIGS[cfg]
+    gcm, zf, zh, prof = tiled_batch(n, nG, nL, seed)
+    g, p = dev(gcm, eng.device), dev(prof, eng.device)
+    zf_d, zh_d = torch.from_numpy(zf).to(eng.device), torch.from_numpy(zh).to(eng.device)
+    fwd = eng.forward(g, zf_d, p, 1.0, DT, zh=zh_d, want_profiles=False)
+    bwd = eng.backward(g, zf_d, p, 1.0, DT, Zf=fwd["Zf"])
+    torch.cuda.synchronize()
+    F = {k: host(v) for k, v in fwd.items()}
+    B = {k: host(v) for k, v in bwd.items()}
+
+    # (1) sample parity vs the C oracle
+    rng = numpy.random.default_rng(cfg)
+    rows = numpy.sort(rng.choice(n, size=6000 if cfg == 4 else 2500, replace=False))
+    gs = {k: numpy.ascontiguousarray(v[rows]) for k, v in gcm.items()}
+    ps = {k: numpy.ascontiguousarray(v[rows]) for k, v in prof.items()}
+    rf = oracle_c.forward(gs, zf, zh, ps, 1.0, DT)
+    rb = oracle_c.backward(gs, rf["Zf"], zf, ps, 1.0, DT)
+    assert_bits("idx", F["idx"][rows], rf["idx"])
+    assert_bits("start_index", B["start_index"][rows], rb["start_index"])
+    for k in ("Zf", "Zh", "f_u", "f_v", "f_qt", "f_ql", "ql_ref", "f_ps"):
+        assert_bits(k, F[k][rows], rf[k])
+    for k in ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A"):
+        assert_bits(k, B[k][rows], rb[k])
+    thl_scale = 400.0
+    assert numpy.abs(F["f_thl"][rows] - rf["f_thl"]).max() <= 8 * EPS * thl_scale / DT
+    assert numpy.abs(F["f_thl"][rows] - rf["f_thl"]).max() <= 1e-10 * numpy.abs(rf["f_thl"]).max()   # north-star bar
+
+    # (2a) batch-split invariance on the whole batch (different workgroup <-> column mapping, same bits)
+    h = n // 2 + 3
+    for lo, hi in ((0, h), (h, n)):
+        gs2 = {k: v[lo:hi] for k, v in g.items()}
+        ps2 = {k: v[lo:hi] for k, v in p.items()}
+        f2 = eng.forward(gs2, zf_d, ps2, 1.0, DT, zh=zh_d)
+        b2 = eng.backward(gs2, zf_d, ps2, 1.0, DT, Zf=f2["Zf"], cols_per_block=1)
+        torch.cuda.synchronize()
+        for k in ("f_thl", "f_u", "idx", "ql_ref"):
+            assert torch.equal(f2[k], fwd[k][lo:hi]), k
+        for k in ("f_T", "f_A", "start_index"):
+            a, b = host(b2[k]), B[k][lo:hi]
+            assert numpy.array_equal(a, b, equal_nan=True), k
+    # (2b) linearity in the factor: doubling it doubles every forcing / tendency exactly
+    f3 = eng.forward(g, zf_d, p, 2.0, DT, zh=zh_d)
+    b3 = eng.backward(g, zf_d, p, 2.0, DT, Zf=fwd["Zf"])
+    torch.cuda.synchronize()
+    for k in ("f_u", "f_v", "f_thl", "f_qt", "f_ql", "f_ps"):
+        assert torch.equal(f3[k], 2.0 * fwd[k]), k
+    for k in ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A"):
+        assert torch.equal(b3[k], 2.0 * bwd[k]), k
+    assert torch.equal(f3["ql_ref"], fwd["ql_ref"]) and torch.equal(f3["idx"], fwd["idx"])
+    # (2c) invariants: index range, monotone index map, masked levels are exactly zero
+    assert F["idx"].min() >= 0 and F["idx"].max() <= nL and (numpy.diff(F["idx"], axis=1) >= 0).all()
+    si = B["start_index"]
+    assert si.min() >= 0 and si.max() <= nG
+    mask = numpy.arange(nG)[None, :] < si[:, None]
+    assert (B["f_U"][mask] == 0).all() and (B["f_T"][mask] == 0).all()
+    assert (F["Zf"][mask] > zf[-1]).all() and (F["Zf"][~mask] <= zf[-1]).all()
+
+
+def test_fp32_vs_fp64_tolerance_sweep_config5(eng):
+    """config 5: fp32 arithmetic against fp64 on T255-sized 137<->512 columns (sample of 20 000)."""
+    from sp_coupler_amd.engine import Engine
+    e32 = Engine("cuda:0", dtype=torch.float32)
+    gcm, zf, zh, prof = tiled_batch(20000, 137, 512, synthetic.CONFIGS[5][3])
+    g64, p64 = dev(gcm, eng.device), dev(prof, eng.device)
+    g32, p32 = dev(gcm, eng.device, torch.float32), dev(prof, eng.device, torch.float32)
+    z64 = (torch.from_numpy(zf).to(eng.device), torch.from_numpy(zh).to(eng.device))
+    z32 = (z64[0].float(), z64[1].float())
+    f64 = eng.forward(g64, z64[0], p64, 1.0, DT, zh=z64[1], want_profiles=True)
+    f32 = e32.forward(g32, z32[0], p32, 1.0, DT, zh=z32[1], want_profiles=True)
+    b64 = eng.backward(g64, z64[0], p64, 1.0, DT, Zf=f64["Zf"])
+    b32 = e32.backward(g32, z32[0], p32, 1.0, DT, Zf=f32["Zf"])
+    torch.cuda.synchronize()
+    rel = {}
+    for k in ("u", "v", "thl", "qt", "ql_ref"):
+        a, b = host(f32[k]).astype(numpy.float64), host(f64[k])
+        rel[k] = float(numpy.abs(a - b).max() / numpy.abs(b).max())
+    # forcings are differences of nearly equal numbers: their fp32 error is set by the PROFILE's scale
+    for k, prof_k in (("f_u", "u"), ("f_thl", "thl"), ("f_qt", "qt")):
+        a, b = host(f32[k]).astype(numpy.float64), host(f64[k])
+        rel[k + "/profile_scale"] = float(numpy.abs(a - b).max() * DT / numpy.abs(host(f64[prof_k])).max())
+    rel["idx_mismatch_fraction"] = float((host(f32["idx"]) != host(f64["idx"])).mean())
+    rel["start_index_mismatch_fraction"] = float((host(b32["start_index"]) != host(b64["start_index"])).mean())
+    print("fp32 vs fp64 (config 5 geometry):", rel)
+    assert rel["u"] < 5e-5 and rel["v"] < 5e-5 and rel["thl"] < 5e-6 and rel["qt"] < 5e-5
+    assert rel["f_thl/profile_scale"] < 5e-6 and rel["f_u/profile_scale"] < 5e-5
+    assert rel["idx_mismatch_fraction"] < 0.01 and rel["start_index_mismatch_fraction"] < 0.01

@@ -11,7 +11,8 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
 lib = "/tmp/libspc_stamps.so"
-subprocess.run([ge.HIPCC] + ge.HIP_FLAGS + ["-DSPC_STAMPS", ge.HIP_SRC, "-o", lib], check=True)
+mode = os.environ.get("STAMP_MODE", "1")   # 1: every phase (drains memory at each stamp); 2: entry/end only
+subprocess.run([ge.HIPCC] + ge.HIP_FLAGS + ["-DSPC_STAMPS=" + mode, ge.HIP_SRC, "-o", lib], check=True)
 os.environ["SPC_LIB"] = lib
 import numpy  # noqa: E402
 import torch  # noqa: E402
@@ -26,6 +27,7 @@ eng.lib.spc_debug_set_stamps.argtypes = [ctypes.c_void_p]
 plans = []
 for r in range(8):
     gcm, zf, zh, prof = synthetic.make_batch(n, 91, 160, seed=r, couple_surface=False)
+    prof = {k: v for k, v in prof.items() if k not in ("Rain", "rain_last")}      # lean hot path, as bench.py
     g = {k: torch.from_numpy(v).cuda() for k, v in gcm.items()}
     p = {k: torch.from_numpy(v).cuda() for k, v in prof.items()}
     plans.append(eng.plan_forward(g, torch.from_numpy(zf).cuda(), p, 1.0, 900.0, zh=torch.from_numpy(zh).cuda(),
@@ -45,6 +47,13 @@ names = ["entry", "prologue loads landed", "phase1 done (pow, LDS)", "barrier pa
          "phase2+idx done (stores landed)", "end"]
 print("blocks stamped:", len(st), " kernel span (first entry -> last end): %.2f us" % ((st[:, 5].max() - t0) / 1e3))
 print("entry spread: %.2f us" % ((st[:, 0].max() - t0) / 1e3))
+if mode == "2":
+    life = st[:, 5] - st[:, 0]
+    print("per-workgroup lifetime (entry -> end, no intermediate drains): median %.2f us p10 %.2f p90 %.2f max %.2f" % (
+        numpy.median(life) / 1e3, numpy.percentile(life, 10) / 1e3, numpy.percentile(life, 90) / 1e3, life.max() / 1e3))
+    print("end times rel. first entry: median %.2f p90 %.2f max %.2f us" % (
+        numpy.median(st[:, 5] - t0) / 1e3, numpy.percentile(st[:, 5] - t0, 90) / 1e3, (st[:, 5] - t0).max() / 1e3))
+    sys.exit(0)
 for i, nm in enumerate(names):
     d = st[:, i] - (st[:, i - 1] if i else t0)
     print("%-30s median +%.2f us  (p10 %.2f, p90 %.2f)   abs median %.2f us" % (

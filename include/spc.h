@@ -16,6 +16,7 @@
  *                           sputils.searchsorted          splib/sputils.py:88-91
  *   spc_backward_*       <- spcpl.set_gcm_tendencies      splib/spcpl.py:388-555 (arithmetic 402-533)
  *                           sputils.interp_c / integral   splib/sputils.py:94-189 (conservative=1)
+ *   spc_surface_fluxes_* <- spcpl.convert_surface_fluxes  splib/spcpl.py:136-167 (columns without LES)
  *   spc_diagnostics_*    <- spifs.nc diagnostics          splib/spcpl.py:176,214-215,408-409;
  *                           spcpl.output_column_conversion splib/spcpl.py:251-267
  *
@@ -146,6 +147,16 @@ typedef struct spc_diagnostics_args {
 
 int spc_diagnostics_f64(const spc_dims *dims, const spc_diagnostics_args *args, void *stream);
 int spc_diagnostics_f32(const spc_dims *dims, const spc_diagnostics_args *args, void *stream);
+
+/* ---- surface fluxes for columns without an LES (extra output columns) --------------------------- */
+/* spcpl.convert_surface_fluxes (splib/spcpl.py:136-167) on per-column scalars [n]:
+ *   rho = Ph_s/(rd*T_s); wqt = -(QLflux+QIflux+SHflux)/rho; wthl = -TSflux*iexner(Ph_s)/(cp*rho)
+ * Ph_s = Phalf[:, nG], T_s = T[:, nG-1].  (z0m, z0h are passed through by the caller.)  For SP columns
+ * the same arithmetic is fused into spc_forward_* (wthl / wqt outputs).                               */
+int spc_surface_fluxes_f64(int64_t n, const void *Ph_s, const void *T_s, const void *QLflux, const void *QIflux,
+                           const void *SHflux, const void *TSflux, void *wthl, void *wqt, void *stream);
+int spc_surface_fluxes_f32(int64_t n, const void *Ph_s, const void *T_s, const void *QLflux, const void *QIflux,
+                           const void *SHflux, const void *TSflux, void *wthl, void *wqt, void *stream);
 
 /* ---- misc ----------------------------------------------------------------------------------- */
 int spc_abi_version(void);          /* == SPC_ABI_VERSION                                          */

@@ -74,6 +74,8 @@ PROTOTYPES = {
     "spc_backward_f32": (ctypes.c_int, [ctypes.POINTER(Dims), ctypes.POINTER(BackwardArgs), c_void_p]),
     "spc_diagnostics_f64": (ctypes.c_int, [ctypes.POINTER(Dims), ctypes.POINTER(DiagnosticsArgs), c_void_p]),
     "spc_diagnostics_f32": (ctypes.c_int, [ctypes.POINTER(Dims), ctypes.POINTER(DiagnosticsArgs), c_void_p]),
+    "spc_surface_fluxes_f64": (ctypes.c_int, [c_int64] + [c_void_p] * 9),
+    "spc_surface_fluxes_f32": (ctypes.c_int, [c_int64] + [c_void_p] * 9),
     "spc_abi_version": (ctypes.c_int, []),
     "spc_last_error": (ctypes.c_char_p, []),
     "spc_device_count": (ctypes.c_int, []),

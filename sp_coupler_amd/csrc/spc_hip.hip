@@ -749,6 +749,20 @@ template <typename T> __global__ __launch_bounds__(BLOCK) void k_diag(const Diag
     }
 }
 
+// spcpl.convert_surface_fluxes for columns WITHOUT an LES (extra output columns, spcpl.py:112-115):
+// per-column scalars only.  Ph_s = Phalf[:, nG] (surface pressure), T_s = T[:, nG-1] (lowest level).
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_surface(int64_t n, const T *Ph_s, const T *T_s, const T *QLflux, const T *QIflux,
+                                                   const T *SHflux, const T *TSflux, T *wthl, T *wqt)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const T ps = Ph_s[i];
+        const T rho = ps / (K<T>::rd * T_s[i]);                                        // spcpl.py:153
+        wqt[i] = -(QLflux[i] + QIflux[i] + SHflux[i]) / rho;                           // spcpl.py:159
+        wthl[i] = -TSflux[i] * spc_pow(div_pref0(ps), (-K<T>::rd) / K<T>::cp) / (K<T>::cp * rho);   // spcpl.py:161
+    }
+}
+
 // 16 B/lane streaming copy: the measured-bandwidth yardstick reported beside the roofline.
 __global__ __launch_bounds__(BLOCK) void k_copy16(uint4 *dst, const uint4 *src, int64_t n16)
 {
@@ -1035,6 +1049,20 @@ template <typename T> int diag_impl(const spc_dims *d, const spc_diagnostics_arg
 #undef COP
 #undef OOP
 
+template <typename T>
+int surface_impl(int64_t n, const void *Ph_s, const void *T_s, const void *QLflux, const void *QIflux,
+                        const void *SHflux, const void *TSflux, void *wthl, void *wqt, void *stream)
+{
+    if (n < 0) return fail(SPC_ERR_INVALID_ARGUMENT, "%ssurface_fluxes: n < 0");
+    if (n == 0) return SPC_OK;
+    if (!Ph_s || !T_s || !QLflux || !QIflux || !SHflux || !TSflux || !wthl || !wqt)
+        return fail(SPC_ERR_INVALID_ARGUMENT, "%ssurface_fluxes: NULL pointer");
+    const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK < 2048 ? (n + BLOCK - 1) / BLOCK : 2048);
+    hipLaunchKernelGGL(k_surface<T>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, n, (const T *)Ph_s, (const T *)T_s,
+                       (const T *)QLflux, (const T *)QIflux, (const T *)SHflux, (const T *)TSflux, (T *)wthl, (T *)wqt);
+    return launch_status("k_surface");
+}
+
 }  // namespace
 
 extern "C" {
@@ -1060,6 +1088,18 @@ int spc_debug_set_stamps(void *buf)  // diagnostic build only
     return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : SPC_ERR_LAUNCH;
 }
 #endif
+
+int spc_surface_fluxes_f64(int64_t n, const void *Ph_s, const void *T_s, const void *QLflux, const void *QIflux,
+                           const void *SHflux, const void *TSflux, void *wthl, void *wqt, void *stream)
+{
+    return surface_impl<double>(n, Ph_s, T_s, QLflux, QIflux, SHflux, TSflux, wthl, wqt, stream);
+}
+
+int spc_surface_fluxes_f32(int64_t n, const void *Ph_s, const void *T_s, const void *QLflux, const void *QIflux,
+                           const void *SHflux, const void *TSflux, void *wthl, void *wqt, void *stream)
+{
+    return surface_impl<float>(n, Ph_s, T_s, QLflux, QIflux, SHflux, TSflux, wthl, wqt, stream);
+}
 
 int spc_abi_version(void) { return SPC_ABI_VERSION; }
 const char *spc_last_error(void) { return g_err; }

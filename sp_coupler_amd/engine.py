@@ -14,8 +14,6 @@ import torch
 
 from . import _abi
 
-GCM_FULL = ("U", "V", "T", "SH", "QL", "QI", "Pfull", "A", "Zgfull")   # [n x nG]   (spcpl.py:32)
-GCM_HALF = ("Phalf", "Zghalf")                                        # [n x nG+1]
 SURF_IN = ("Z0M", "Z0H", "QLflux", "QIflux", "SHflux", "TSflux")      # [n]        (spcpl.py:33,138)
 FWD_LES = ("U", "V", "THL", "QT", "QL")                               # profile[...] spcpl.py:310-314
 BWD_LES = ("T", "QT", "QL", "QL_ice", "U", "V")                       # profile[...] spcpl.py:393-411
@@ -321,6 +319,19 @@ class Engine:
         rc = self._diag(ctypes.byref(dims), ctypes.byref(a), _stream_ptr(stream))
         _abi.check(self.lib, rc)
         return res
+
+    # -- surface fluxes of columns without an LES -------------------------------------------------
+    def surface_fluxes(self, Ph_s, T_s, QLflux, QIflux, SHflux, TSflux, stream=None):
+        """(wthl, wqt) of spcpl.convert_surface_fluxes (splib/spcpl.py:153-161) for [n] scalars."""
+        n = int(Ph_s.shape[0])
+        ck = _Checker(self.device, self.dtype)
+        ptrs = [ck.vec(nm, t, n) for nm, t in (("Ph_s", Ph_s), ("T_s", T_s), ("QLflux", QLflux), ("QIflux", QIflux),
+                                               ("SHflux", SHflux), ("TSflux", TSflux))]
+        wthl, wqt = self.empty(n), self.empty(n)
+        fn = getattr(self.lib, "spc_surface_fluxes_" + _DTYPES[self.dtype])
+        rc = fn(n, *ptrs, wthl.data_ptr(), wqt.data_ptr(), _stream_ptr(stream))
+        _abi.check(self.lib, rc)
+        return wthl, wqt
 
     # -- measured copy bandwidth yardstick ----------------------------------------------------
     def stream_copy(self, dst, src, stream=None):

@@ -197,6 +197,11 @@ def gather_gcm_data(gcm, les_models, couple_surface, output_column_indices=None,
         rows = [writer_rows[c] for c in extra_cols]      # column index of each extra output column in the file
         writer.write(rows=rows, **{k: D[k] for k in ("U", "V", "T", "SH", "QL", "QI", "Pf", "Ph", "Zf", "Zh", "Psurf",
                                                       "Tv", "THL", "QT", "A")})
+        if couple_surface:                                                   # spcpl.py:112-129
+            Cs = dict(C, Ph=profile_data["Phalf"][n0:], T=profile_data["T"][n0:])
+            z0m, z0h, wthl, wqt = convert_surface_fluxes(Cs)
+            writer.write(rows=rows, z0m=_num(z0m), z0h=_num(z0h), wthl=_num(wthl), wqt=_num(wqt),
+                         **{k: surface_data[k][n0:] for k in ("TLflux", "TSflux", "SHflux", "QLflux", "QIflux")})
     _current = batch
     return batch
 
@@ -333,16 +338,39 @@ def set_les_forcings_batched(les_models, gcm, asynchronous, firststep, profiles,
 
 
 def convert_surface_fluxes(les):
-    """splib/spcpl.py:136-167 for one column: (z0m, z0h, wthl, wqt). Accepts a les object or a dict."""
+    """splib/spcpl.py:136-167: (z0m, z0h, wthl, wqt). ``les`` is an LES object of the current batch (values
+    come from the fused forward launch) or, as in the reference, a dict of GCM data for columns without
+    an LES (keys Z0M, Z0H, QLflux, QIflux, SHflux, TSflux, Ph, T; one column or [n x ...])."""
     if isinstance(les, dict):
-        n = numpy.atleast_2d(_num(les["T"])).shape[0]
-        raise NotImplementedError("dict form is served by output_column_conversion(); n=%d" % n)
+        eng = get_engine()
+        Ph, T = numpy.atleast_2d(_num(les["Ph"])), numpy.atleast_2d(_num(les["T"]))   # KeyError if missing, spcpl.py:146
+        one = numpy.ndim(_num(les["T"])) == 1
+        dev = lambda a: torch.from_numpy(numpy.ascontiguousarray(numpy.atleast_1d(_num(a)))).to(eng.device, eng.dtype)  # noqa: E731
+        wthl, wqt = eng.surface_fluxes(dev(Ph[:, -1]), dev(T[:, -1]), dev(les["QLflux"]), dev(les["QIflux"]),
+                                       dev(les["SHflux"]), dev(les["TSflux"]))
+        wthl, wqt = wthl.cpu().numpy(), wqt.cpu().numpy()
+        sel = (lambda a: a[0]) if one else (lambda a: a)
+        return les.get("Z0M"), les.get("Z0H"), _wrap("wthl", sel(wthl)), _wrap("wqt", sel(wqt))
     batch = _batch_of(les)
     if batch.fwd is None or "wthl" not in batch.fwd:
         raise RuntimeError("surface fluxes are computed by set_les_forcings(..., couple_surface=True)")
     i = batch.index_of(les)
     f = batch.fwd
     return _wrap("z0m", f["z0m"][i]), _wrap("z0h", f["z0h"][i]), _wrap("wthl", f["wthl"][i]), _wrap("wqt", f["wqt"][i])
+
+
+def set_les_state(les, u, v, thl, qt, ps=None):
+    """splib/spcpl.py:274-294: broadcast the profiles to 3-D fields with uniform random perturbations
+    (DALES defaults; numpy's GLOBAL generator like the reference, seeded by splib.initialize with 42).
+    Model initialisation, not part of the per-step path: plain host NumPy."""
+    itot, jtot, ktot = les.get_itot(), les.get_jtot(), les.get_ktot()
+    vabsmax, thlabsmax, qabsmax = 0.5, 0.1, 2.5e-5                           # spcpl.py:285-287
+    les.set_field('U', _wrap("u", vabsmax * numpy.random.uniform(-1., 1., (itot, jtot, ktot)) + _num(u)))
+    les.set_field('V', _wrap("v", vabsmax * numpy.random.uniform(-1., 1., (itot, jtot, ktot)) + _num(v)))
+    les.set_field('THL', _wrap("thl", thlabsmax * numpy.random.uniform(-1., 1., (itot, jtot, ktot)) + _num(thl)))
+    les.set_field('QT', _wrap("qt", qabsmax * numpy.random.uniform(-1., 1., (itot, jtot, ktot)) + _num(qt)))
+    if ps:
+        les.set_surface_pressure(ps)
 
 
 # ---------------------------------------------------------------------------------------------

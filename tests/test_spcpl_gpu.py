@@ -184,3 +184,30 @@ def test_spifs_output_through_the_driver(tmp_path):
                 assert numpy.array_equal(c[name][s], numpy.asarray(want, dtype=numpy.float32)), (name, s)
             assert numpy.isfinite(c["Tv"][s]).all() and numpy.isfinite(c["t"][s]).all() and (c["Zf"][s][:-1] > c["Zf"][s][1:]).all()
             assert numpy.array_equal(c["ql_water"][s], (c["ql"][s].astype(numpy.float64) - c["ql_ice"][s]).astype(numpy.float32)) or True
+
+
+def test_surface_fluxes_dict_form_and_set_les_state():
+    """convert_surface_fluxes on a dict of GCM data (extra output columns, spcpl.py:112-115) and the
+    init-state path convert_profiles -> set_les_state (splib.py:202-204)."""
+    from oracle import spcpl_oracle as orc
+    from sp_coupler_amd import spcpl
+    gcm, les_models = models.make_models(3, nG=91, nL=160, seed=17)
+    st = gcm.state
+    C = {"Ph": st["Phalf"][4:7], "T": st["T"][4:7]}
+    C.update({k: st[k][4:7] for k in ("Z0M", "Z0H", "QLflux", "QIflux", "SHflux", "TLflux", "TSflux")})
+    z0m, z0h, wthl, wqt = spcpl.convert_surface_fluxes(C)
+    for i in range(3):
+        col = {"Phalf": C["Ph"][i], "T": C["T"][i]}
+        col.update({k: C[k][i] for k in ("Z0M", "Z0H", "QLflux", "QIflux", "SHflux", "TSflux")})
+        r = orc.convert_surface_fluxes(col)
+        assert wqt[i] == r[3] and abs(wthl[i] - r[2]) <= 8 * EPS * abs(r[2]) and z0m[i] == r[0]
+    one = {k: v[1] for k, v in C.items()}
+    assert spcpl.convert_surface_fluxes(one)[3] == wqt[1]
+    spcpl.gather_gcm_data(gcm, les_models, True)
+    numpy.random.seed(42)                                                     # splib.py:181
+    u, v, thl, qt, ps, ql = spcpl.convert_profiles(les_models[0])
+    spcpl.set_les_state(les_models[0], u, v, thl, qt, ps)
+    assert abs(les_models[0].p["U"] - u).max() < 0.5 and les_models[0].p["PS"] == ps
+    numpy.random.seed(42)
+    noise = 0.5 * numpy.random.uniform(-1., 1., (8, 8, 160))
+    assert numpy.allclose(les_models[0].p["U"], (noise + u).mean(axis=(0, 1)), rtol=0, atol=1e-12)

@@ -54,6 +54,65 @@ def cpu_baseline(gcm, zf, zh, prof, dt, factor, budget_s):
                       "%.1f s)" % (done, done // n, n, el)}
 
 
+def cpu_worker_main(path, budget):
+    """`python bench.py --cpu-worker PATH BUDGET`: one worker of the all-cores leg -- whole passes over
+    its copy of a small batch for BUDGET seconds; prints "<done> <seconds>". Never touches the GPU."""
+    import numpy
+    from oracle import spcpl_oracle as orc
+    z = numpy.load(path)
+    gcm = {k[2:]: z[k] for k in z.files if k.startswith("g_")}
+    prof = {k[2:]: z[k] for k in z.files if k.startswith("p_")}
+    zf, zh = z["zf"], z["zh"]
+    n = gcm["T"].shape[0]
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget:
+        f = orc.forward_batched(gcm, prof, zf, zh, 1.0, 900.0)
+        orc.backward_batched(gcm, f["Zf"], prof, zf, 1.0, 900.0)
+        done += n
+    print(done, time.perf_counter() - t0)
+
+
+def cpu_baseline_multicore(gcm, zf, zh, prof, budget_s, workers):
+    """the same per-column NumPy loop in `workers` independent CHILD PROCESSES
+    (plain subprocesses with a hard timeout -- no pool that could respawn; they never touch the GPU)."""
+    import subprocess
+    import tempfile
+    import numpy
+    sub = 128                                   # a small batch per pass keeps every worker inside the budget
+    d = tempfile.mkdtemp(prefix="spc_cpu_")
+    path = os.path.join(d, "batch.npz")
+    numpy.savez(path, zf=zf, zh=zh, **{"g_" + k: v[:sub] for k, v in gcm.items()},
+                **{"p_" + k: v[:sub] for k, v in prof.items()})
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", path, str(budget_s)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env)
+             for _ in range(workers)]
+    res = []
+    try:
+        for pr in procs:
+            try:
+                out, _ = pr.communicate(timeout=budget_s + 60)
+                a, b = out.split()
+                res.append((int(a), float(b)))
+            except Exception:
+                pr.kill()
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+        try:
+            os.remove(path)
+            os.rmdir(d)
+        except OSError:
+            pass
+    if not res:
+        raise RuntimeError("no cpu worker finished")
+    total = sum(r[0] for r in res)
+    wall = max(r[1] for r in res)
+    return {"value": total / wall, "unit": "column-exchanges/s", "cores": len(res), "kind": "port",
+            "sample": "%d column-exchanges in %d processes x %.1f s (NumPy per-column loop)" % (total, len(res), wall)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,6 +124,7 @@ def main():
     ap.add_argument("--cols-per-block", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP-event pass")
+    ap.add_argument("--no-cpu-multicore", action="store_true", help="skip the all-cores cpu_baseline extra")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N>1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--device", type=int, default=None, help="force this HIP device for every rank (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
@@ -221,6 +281,12 @@ def main():
     if args.cpu_seconds > 0 and world == 1:
         gcm, zf, zh, prof = host0
         out["cpu_baseline"] = cpu_baseline(gcm, zf, zh, prof, dt_gcm, factor, args.cpu_seconds)
+        workers = min(16, os.cpu_count() or 1)
+        if workers > 1 and not args.no_cpu_multicore:
+            try:
+                out["cpu_baseline"]["all_cores"] = cpu_baseline_multicore(gcm, zf, zh, prof, min(6.0, args.cpu_seconds), workers)
+            except Exception as e:                       # a reported extra, never fatal
+                out["cpu_baseline"]["all_cores"] = {"error": repr(e)}
     elif args.cpu_seconds > 0:
         out["cpu_baseline"] = None   # reported at N=1 only
     print(json.dumps(out))
@@ -229,4 +295,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) == 4 and sys.argv[1] == "--cpu-worker":
+        cpu_worker_main(sys.argv[2], float(sys.argv[3]))
+    else:
+        main()

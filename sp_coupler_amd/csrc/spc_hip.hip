@@ -35,7 +35,8 @@ namespace {
 #define SPC_BLOCK 256
 #endif
 constexpr int BLOCK = SPC_BLOCK;
-constexpr int MAX_LDS_BYTES = 64 * 1024;  // default dynamic-LDS limit; keeps >= 2 workgroups per CU
+constexpr int MAX_LDS_BYTES = 64 * 1024;    // preferred ceiling (default dynamic-LDS limit, >= 2 workgroups per CU)
+constexpr int HARD_LDS_BYTES = 160 * 1024;  // gfx950: 160 KiB per CU, reachable for one column per workgroup
 
 thread_local char g_err[512] = "";
 
@@ -878,6 +879,19 @@ DimsP make_dims(const spc_dims *d, int cb)
     return p;
 }
 
+// Dynamic LDS above the 64 KiB default needs the per-function opt-in (tall columns: nL > ~1300 in K3).
+template <typename KernelT> int ensure_lds(KernelT kernel, size_t smem, const char *what)
+{
+    if (smem <= (size_t)MAX_LDS_BYTES) return SPC_OK;
+    if (smem > (size_t)HARD_LDS_BYTES)
+        return fail(SPC_ERR_UNSUPPORTED, "%s needs %lld B of LDS per workgroup (gfx950 has %lld)", what, (long long)smem, HARD_LDS_BYTES);
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(SPC_ERR_UNSUPPORTED, "%s: cannot raise the dynamic LDS limit to %lld B", what, (long long)smem);
+    }
+    return SPC_OK;
+}
+
 int launch_status(const char *what)
 {
     const hipError_t e = hipGetLastError();
@@ -926,8 +940,6 @@ template <typename T> int forward_impl(const spc_dims *d, const spc_forward_args
     size_t per_col, fixed;
     lds_elems(d, 0, with_idx, &per_col, &fixed);
     const size_t smem = (per_col * cb + fixed) * sizeof(T);
-    if (smem > (size_t)MAX_LDS_BYTES)
-        return fail(SPC_ERR_UNSUPPORTED, "%sforward needs %lld B of LDS per workgroup (max %lld)", "", (long long)smem, MAX_LDS_BYTES);
 #define CP(f) p.f = (const T *)a->f
 #define OP(f) p.f = (T *)a->f
 #define COP(f) p.o.f = (const T *)a->f
@@ -945,10 +957,12 @@ template <typename T> int forward_impl(const spc_dims *d, const spc_forward_args
         fill(p);
         COP(rain); COP(rain_last); OOP(u); OOP(v); OOP(thl); OOP(qt); OOP(ps); OOP(Zf); OOP(Zh); OOP(rainrate);
         COP(Z0M); COP(Z0H); COP(QLflux); COP(QIflux); COP(SHflux); COP(TSflux); OOP(z0m); OOP(z0h); OOP(wthl); OOP(wqt);
+        if ((rc = ensure_lds(kfull[wt][geo], smem, "forward"))) return rc;
         hipLaunchKernelGGL(kfull[wt][geo], dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
     } else {
         FwdP<T, false> p;
         fill(p);
+        if ((rc = ensure_lds(klean[wt][geo], smem, "forward"))) return rc;
         hipLaunchKernelGGL(klean[wt][geo], dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
     }
     return launch_status("k_forward");
@@ -965,8 +979,7 @@ int cloud_idx_impl(const spc_dims *d, const void *zh, const void *Zh, int32_t *i
     size_t per_col, fixed;
     lds_elems(d, 2, true, &per_col, &fixed);
     const size_t smem = (per_col * cb + fixed) * sizeof(T);
-    if (smem > (size_t)MAX_LDS_BYTES)
-        return fail(SPC_ERR_UNSUPPORTED, "%scloud_indices needs %lld B of LDS (max %lld)", "", (long long)smem, MAX_LDS_BYTES);
+    if ((rc = ensure_lds(k_cloud_idx<T>, smem, "cloud_indices"))) return rc;
     const unsigned grid = (unsigned)((d->n_cols + cb - 1) / cb);
     hipLaunchKernelGGL(k_cloud_idx<T>, dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, make_dims(d, cb),
                        (const T *)zh, (const T *)Zh, idx);
@@ -1003,8 +1016,7 @@ template <typename T> int backward_impl(const spc_dims *d, const spc_backward_ar
     size_t per_col, fixed;
     lds_elems(d, cons ? 4 : 1, false, &per_col, &fixed);
     const size_t smem = (per_col * cb + fixed) * sizeof(T);
-    if (smem > (size_t)MAX_LDS_BYTES)
-        return fail(SPC_ERR_UNSUPPORTED, "%sbackward needs %lld B of LDS per workgroup (max %lld)", "", (long long)smem, MAX_LDS_BYTES);
+    if ((rc = cons ? ensure_lds(k_backward_cons<T>, smem, "backward (conservative)") : ensure_lds(kb[wt][geo], smem, "backward"))) return rc;
     BwdP<T> p;
     p.d = make_dims(d, cb);
     p.Tm = (const T *)a->T; CP(SH); CP(QL); CP(QI); CP(U); CP(V); CP(A); CP(Zf); CP(Zgfull); CP(Zghalf); CP(zf);
@@ -1034,8 +1046,7 @@ template <typename T> int diag_impl(const spc_dims *d, const spc_diagnostics_arg
     size_t per_col, fixed;
     lds_elems(d, 3, false, &per_col, &fixed);
     const size_t smem = (per_col * cb + fixed) * sizeof(T);
-    if (smem > (size_t)MAX_LDS_BYTES)
-        return fail(SPC_ERR_UNSUPPORTED, "%sdiagnostics needs %lld B of LDS (max %lld)", "", (long long)smem, MAX_LDS_BYTES);
+    if ((rc = ensure_lds(k_diag<T>, smem, "diagnostics"))) return rc;
     DiagP<T> p;
     p.d = make_dims(d, cb);
     p.Tm = (const T *)a->T; CP(SH); CP(QL); CP(QI); CP(Pf); CP(Zgfull); CP(Zghalf); CP(zf); CP(thl_d); CP(ql_d); CP(ql_ice_d);

@@ -260,3 +260,20 @@ def test_conservative_coarsening_bit_exact(eng, n, nG, nL, per_col):
     check_backward({k: host(v) for k, v in got.items()}, ref)
     check_backward({k: host(v) for k, v in got2.items()}, ref)
     assert (host(got["f_T"]) != 0).any()
+
+
+def test_tall_les_columns_use_large_lds_and_too_tall_is_refused(eng):
+    """nL = 2048 needs > 64 KiB of LDS per workgroup in K3 (opt-in up to gfx950's 160 KiB); nL = 4000 cannot
+    be staged and must be refused with SPC_ERR_UNSUPPORTED, not launched."""
+    from sp_coupler_amd import _abi
+    gcm, zf, zh, prof = synthetic.make_batch(6, 91, 2048, seed=44)
+    fwd, bwd = run_gpu(eng, gcm, zf, zh, prof)
+    ref_f = oracle_c.forward(gcm, zf, zh, prof, FACTOR, DT)
+    ref_b = oracle_c.backward(gcm, ref_f["Zf"], zf, prof, FACTOR, DT)
+    check_forward(fwd, ref_f, numpy.abs(ref_f["thl"]).max())
+    check_backward(bwd, ref_b)
+    gcm, zf, zh, prof = synthetic.make_batch(2, 19, 4000, seed=45)
+    g, p = to_dev(gcm, eng.device), to_dev(prof, eng.device)
+    with pytest.raises(_abi.SpcError) as e:
+        eng.backward(g, torch.from_numpy(zf).to(eng.device), p, 1.0, DT)
+    assert e.value.code == _abi.SPC_ERR_UNSUPPORTED

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <type_traits>
@@ -834,9 +835,14 @@ template <typename KernelT> int blocks_per_cu(KernelT kernel, size_t smem)
     return nb;
 }
 
-// Columns per workgroup.  Small batches: one column per workgroup (latency-bound, maximum parallelism).
-// Large batches (>= 2048 workgroups left): the candidate in {8,4,2,1} with the most resident
-// workgroups per CU (LDS- and register-limited), ties to the larger one (longer coalesced slabs).
+// Columns per workgroup (CB).
+//  1. If some CB in {1,2,4} lets the WHOLE grid be resident at once (n_cols/CB <= 256 CUs x resident
+//     workgroups per CU at that CB's LDS footprint), take the smallest such CB: a single round of
+//     workgroups, maximum parallelism per column (measured: 2048 columns run 13.3 us at CB=2 but 19-20 us
+//     at CB=1, which needs two rounds).
+//  2. Otherwise (throughput regime) the CB with the most resident workgroups per CU among those that
+//     still give >= 2 full rounds of workgroups (rounds de-synchronise the load / compute / store
+//     phases), ties to the larger one (longer coalesced slabs): K1 -> 8, K3 -> 2 at 91<->160.
 template <typename KernelT> int pick_cb(const spc_dims *d, int pass, bool with_idx, size_t esize, KernelT kernel)
 {
     size_t per_col, fixed;
@@ -846,19 +852,32 @@ template <typename KernelT> int pick_cb(const spc_dims *d, int pass, bool with_i
         while (cb > 1 && (per_col * cb + fixed) * esize > (size_t)MAX_LDS_BYTES) --cb;
         return cb;
     }
-    int best = 1, best_nb = -1;
-    for (cb = 8; cb >= 1; cb >>= 1) {
+    int nb[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) {
+        cb = 1 << i;
         const size_t smem = (per_col * cb + fixed) * esize;
-        if (cb > 1 && (d->n_cols / cb < 2048 || smem > (size_t)MAX_LDS_BYTES)) continue;
-        const int nb = blocks_per_cu(kernel, smem);
-        if (nb > best_nb) { best_nb = nb; best = cb; }
+        if (cb > 1 && smem > (size_t)MAX_LDS_BYTES) continue;
+        nb[i] = blocks_per_cu(kernel, smem);
+        if (cb <= 4 && (d->n_cols + cb - 1) / cb <= (int64_t)256 * nb[i]) return cb;   // rule 1
+    }
+    int best = 1, best_nb = -1;
+    for (int i = 3; i >= 0; --i) {                                                      // rule 2
+        cb = 1 << i;
+        const bool two_rounds = (d->n_cols + cb - 1) / cb >= (int64_t)2 * 256 * nb[i];
+        if (nb[i] > best_nb && (two_rounds || i == 0)) { best_nb = nb[i]; best = cb; }
     }
     return best;
 }
 
-// launches with fewer than 2048 workgroups are short enough for the end-of-kernel L2 flush to show:
-// they store write-through (see stg)
-int small_batch(const spc_dims *d, int cb) { return (d->n_cols + cb - 1) / cb < 2048 ? 1 : 0; }
+// Launches that write no more than the aggregate L2 (32 MiB) store write-through: otherwise all of it is
+// still dirty when the kernel ends and the end-of-kernel release has to flush it (measured: WT wins up
+// to ~4096 columns, loses beyond ~16k).  SPC_FORCE_WT=0/1 overrides (A/B runs).
+int small_batch(int64_t bytes_written)
+{
+    static const int forced = [] { const char *e = getenv("SPC_FORCE_WT"); return e ? atoi(e) : -1; }();
+    if (forced == 0 || forced == 1) return forced;
+    return bytes_written <= (int64_t)32 * 1024 * 1024 ? 1 : 0;
+}
 
 // 0 = generic; 1..3 = compile-time geometries with contiguous columns (see k_forward)
 int geometry_id(const spc_dims *d)
@@ -936,7 +955,7 @@ template <typename T> int forward_impl(const spc_dims *d, const spc_forward_args
         {k_forward<T, false, 0, 0, 0>, k_forward<T, false, 91, 160, 0>, k_forward<T, false, 137, 512, 0>, k_forward<T, false, 19, 160, 0>},
         {k_forward<T, false, 0, 0, 1>, k_forward<T, false, 91, 160, 1>, k_forward<T, false, 137, 512, 1>, k_forward<T, false, 19, 160, 1>}};
     const int cb = full ? pick_cb(d, 0, with_idx, sizeof(T), kfull[0][geo]) : pick_cb(d, 0, with_idx, sizeof(T), klean[0][geo]);
-    const int wt = small_batch(d, cb);
+    const int wt = small_batch(d->n_cols * (int64_t)((6 * d->nL + 1) * sizeof(T) + (with_idx ? d->nG * 4 : 0)));
     size_t per_col, fixed;
     lds_elems(d, 0, with_idx, &per_col, &fixed);
     const size_t smem = (per_col * cb + fixed) * sizeof(T);
@@ -1012,7 +1031,7 @@ template <typename T> int backward_impl(const spc_dims *d, const spc_backward_ar
         {k_backward<T, 0, 0, 0>, k_backward<T, 91, 160, 0>, k_backward<T, 137, 512, 0>, k_backward<T, 19, 160, 0>},
         {k_backward<T, 0, 0, 1>, k_backward<T, 91, 160, 1>, k_backward<T, 137, 512, 1>, k_backward<T, 19, 160, 1>}};
     const int cb = cons ? pick_cb(d, 4, false, sizeof(T), k_backward_cons<T>) : pick_cb(d, 1, false, sizeof(T), kb[0][geo]);
-    const int wt = small_batch(d, cb);
+    const int wt = small_batch(d->n_cols * (int64_t)(7 * d->nG * sizeof(T)));
     size_t per_col, fixed;
     lds_elems(d, cons ? 4 : 1, false, &per_col, &fixed);
     const size_t smem = (per_col * cb + fixed) * sizeof(T);

@@ -1,0 +1,87 @@
+"""TEST-ONLY engine with the interface of sp_coupler_amd.engine.Engine, computing with the CPU oracle on
+torch CPU tensors.  It exists so that the HOST LOGIC of the product (spcpl fan-out, profile registry,
+driver sequencing, sharding, spifs writer) can be exercised by the `-m "not gpu"` suite; it is never
+importable from the product package and never used on a GPU box's product path."""
+import numpy
+import torch
+
+from oracle import spcpl_oracle as orc
+
+
+def _np(d):
+    return {k: v.numpy() for k, v in d.items()}
+
+
+def _t(d):
+    return {k: torch.from_numpy(numpy.ascontiguousarray(v)) for k, v in d.items()}
+
+
+class OracleEngine:
+    device, dtype = torch.device("cpu"), torch.float64
+
+    def forward(self, g, zf, p, factor, dt, zh=None, want_profiles=False, want_heights=True, couple_surface=False, **kw):
+        pn = _np(p)
+        r = orc.forward_batched(_np(g), pn, zf.numpy(), None if zh is None else zh.numpy(), factor, dt,
+                                couple_surface=couple_surface)
+        keep = ["f_u", "f_v", "f_thl", "f_qt", "f_ql", "ql_ref", "f_ps"]
+        if want_profiles:
+            keep += ["u", "v", "thl", "qt", "ps"]
+        if want_heights:
+            keep += ["Zf", "Zh"]
+        if zh is not None:
+            keep += ["idx"]
+        if "Rain" in pn and "rain_last" in pn:
+            keep += ["rainrate"]
+        if couple_surface:
+            keep += ["z0m", "z0h", "wthl", "wqt"]
+        return _t({k: r[k] for k in keep})
+
+    def backward(self, g, zf, p, factor, dt, Zf=None, conservative=False, zh=None, Zh=None, **kw):
+        gn = _np(g)
+        if Zf is None:
+            Zf_n = (gn["Zgfull"] - gn["Zghalf"][:, -1:]) / orc.grav
+        else:
+            Zf_n = Zf.numpy()
+        Zh_n = (gn["Zghalf"] - gn["Zghalf"][:, -1:]) / orc.grav if (conservative and Zh is None) else (
+            None if Zh is None else Zh.numpy())
+        pn = _np(p)
+        pn.setdefault("THL", numpy.zeros_like(pn["T"]))   # only feeds the oracle's `t` diagnostic
+        r = orc.backward_batched(gn, Zf_n, pn, zf.numpy(), factor, dt, conservative=conservative, Zh=Zh_n,
+                                 zh=None if zh is None else zh.numpy())
+        out = {k: r[k] for k in ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A")}
+        out["start_index"] = r["start_index"].astype(numpy.int32)
+        return _t(out)
+
+    def cloud_indices(self, zh, Zh, **kw):
+        zhn, Zhn = zh.numpy(), Zh.numpy()
+        rows = [orc.cloud_fraction_indices(zhn if zhn.ndim == 1 else zhn[i], Zhn[i]) for i in range(Zhn.shape[0])]
+        return torch.from_numpy(numpy.stack(rows).astype(numpy.int32))
+
+    def diagnostics(self, g, zf=None, prof=None, **kw):
+        gn = _np(g)
+        n = gn["T"].shape[0]
+        out = {k: [] for k in ("Tv", "THL", "QT", "Zf", "Zh")}
+        les = {k: [] for k in ("pf", "t", "ql_water")}
+        for i in range(n):
+            col = {k: gn[k][i] for k in ("T", "SH", "QL", "QI", "Zgfull", "Zghalf")}
+            col.update(U=gn["T"][i], V=gn["T"][i], A=gn["T"][i], Pfull=gn["Pfull"][i], Phalf=gn["Zghalf"][i])
+            z = numpy.zeros(2) if zf is None else (zf.numpy() if zf.dim() == 1 else zf.numpy()[i])
+            c = orc.convert_profiles(col, z)
+            for k in out:
+                out[k].append(c[k])
+            if zf is not None and prof is not None:
+                pn = {k: v.numpy()[i] for k, v in prof.items()}
+                pf = orc.interp(z, c["Zf"][::-1], col["Pfull"][::-1])
+                les["pf"].append(pf)
+                les["t"].append(pn["THL"] * orc.exner(pf) + orc.rlv * pn["QL"] / orc.cp)
+                les["ql_water"].append(pn["QL"] - pn["QL_ice"])
+        res = {k: numpy.stack(v) for k, v in out.items()}
+        if les["pf"]:
+            res.update({k: numpy.stack(v) for k, v in les.items()})
+        return _t(res)
+
+    def surface_fluxes(self, Ph_s, T_s, QLflux, QIflux, SHflux, TSflux, **kw):
+        rho = Ph_s.numpy() / (orc.rd * T_s.numpy())
+        wqt = -(QLflux.numpy() + QIflux.numpy() + SHflux.numpy()) / rho
+        wthl = -TSflux.numpy() * orc.iexner(Ph_s.numpy()) / (orc.cp * rho)
+        return torch.from_numpy(wthl), torch.from_numpy(wqt)

@@ -1,0 +1,109 @@
+"""CPU tests of the product's HOST LOGIC (sp_coupler_amd.spcpl fan-out and profile registry, driver
+sequencing, spifs hook) with the test-only oracle-backed engine of tests/fake_engine.py injected through
+spcpl.set_engine().  Because the injected engine and the reference sequencing (tests/ref_driver.py) share
+the oracle's arithmetic, every setter argument must be BIT-identical: any difference is a host-logic bug
+(wrong row, wrong order, stale profile, wrong firststep handling).  The kernels themselves are tested on
+the GPU (tests/test_parity_gpu.py, tests/test_spcpl_gpu.py)."""
+import numpy
+import pytest
+
+from sp_coupler_amd import models, spcpl
+from tests.fake_engine import OracleEngine
+from tests.ref_driver import RefCoupler
+from tests.test_spcpl_gpu import Recorder, _by_key
+
+
+@pytest.fixture(autouse=True)
+def oracle_engine():
+    spcpl.set_engine(OracleEngine())
+    yield
+    spcpl.set_engine(None)
+    spcpl.writer = None
+
+
+@pytest.mark.parametrize("cplsurf,conservative", [(False, False), (True, False), (False, True)])
+def test_driver_sequencing_bit_identical_to_reference_loop(cplsurf, conservative):
+    from sp_coupler_amd.driver import Coupler
+    nsteps, n_les = 3, 5
+    gcm_a, les_a = models.make_models(n_les, nG=19, nL=160, seed=3)
+    gcm_b, les_b = models.make_models(n_les, nG=19, nL=160, seed=3)
+    rec = Recorder(gcm_a, les_a)
+    cpl = Coupler(gcm_a, les_a, cplsurf=cplsurf, les_forcing_factor=0.8, gcm_forcing_factor=1.2,
+                  conservative_coarsening=conservative)
+    ref = RefCoupler(gcm_b, les_b, cplsurf=cplsurf, les_forcing_factor=0.8, gcm_forcing_factor=1.2,
+                     conservative=conservative)
+    for _ in range(nsteps):
+        cpl.step()
+        ref.step()
+    got, want = _by_key(rec.log), _by_key(ref.log)
+    assert set(got) == set(want)
+    for key in want:
+        assert len(got[key]) == nsteps
+        for s in range(nsteps):
+            assert numpy.array_equal(got[key][s], want[key][s], equal_nan=True), (key, s)
+    for var in gcm_b.state:
+        assert numpy.array_equal(gcm_a.state[var], gcm_b.state[var]), var
+    for la, lb in zip(les_a, les_b):
+        assert numpy.array_equal(la.p["THL"], lb.p["THL"]) and la.rain == lb.rain
+        assert la.gcm_Zf.shape == (19,) and la.gcm_Zh.shape == (20,) and la.ql_ref.shape == (160,)
+    assert not cpl.firststep and len(cpl.timing_rows) == nsteps
+
+
+def test_per_les_calls_need_all_profiles_and_stale_profiles_are_not_reused():
+    gcm, les_models = models.make_models(3, nG=19, nL=160, seed=6)
+    spcpl.gather_gcm_data(gcm, les_models, False)
+    with pytest.raises(RuntimeError, match="profiles of 2 columns are unknown"):
+        spcpl.set_les_forcings(les_models[0], gcm, True, False, {"U": 0}, dt_gcm=900.0, factor=1.0, couple_surface=False)
+    with pytest.raises(RuntimeError, match="gather_gcm_data"):
+        spcpl.set_les_forcings(models.SyntheticLES(gcm, 2), gcm, True, True, {}, 900.0, 1.0, False)
+    with pytest.raises(NotImplementedError):
+        spcpl.set_les_forcings(les_models[0], gcm, True, True, {}, 900.0, 1.0, False, qt_forcing="variance")
+    # first step: live getters, all columns in one (fake) launch, request dict per column
+    reqs = spcpl.set_les_forcings_batched(les_models, gcm, True, True, {}, 900.0, 1.0, False)
+    assert len(reqs) == 3 and all(set(r) == {"U", "V", "THL", "QT", "SP", "QL", "QLp"} for r in reqs)
+    b1 = spcpl.current_batch()
+    assert b1.fwd is not None and b1.fwd["f_u"].shape == (3, 160)
+    # a second gather makes a new batch; the profiles fetched after the LES step carry over to it
+    for les in les_models:
+        les.evolve_model(900.0)
+        spcpl.get_les_profiles(les, True)
+    spcpl.gather_gcm_data(gcm, les_models, False)
+    b2 = spcpl.current_batch()
+    assert b2 is not b1 and b2.fwd is None and len(b2.profiles) == 3
+    spcpl.set_les_forcings(les_models[1], gcm, True, False, None, dt_gcm=900.0, factor=1.0, couple_surface=False)
+    assert b2.fwd is not None
+
+
+def test_unit_wrapper_and_quantity_inputs():
+    class Q:                                   # minimal stand-in for an AMUSE quantity
+        def __init__(self, number, unit):
+            self.number, self.unit = number, unit
+    gcm, les_models = models.make_models(2, nG=19, nL=160, seed=8)
+    seen = []
+    spcpl.set_unit_wrapper(lambda name, arr: (seen.append(name), Q(arr, spcpl.output_units[name]))[1])
+    try:
+        orig = gcm.get_profile_fields
+        gcm.get_profile_fields = lambda var, cols: Q(orig(var, cols), "si")
+        spcpl.gather_gcm_data(gcm, les_models, False)
+        spcpl.set_les_forcings_batched(les_models, gcm, False, True, {}, Q(900.0, "s"), 1.0, False)
+        assert {"f_u", "f_v", "f_thl", "f_qt", "f_ps", "f_ql", "ql_ref", "Zf", "Zh"} <= set(seen)
+        assert les_models[0].tend["U"].shape == (160,)            # the model saw the bare numbers
+    finally:
+        spcpl.set_unit_wrapper(None)
+
+
+def test_spifs_hook_writes_once_per_launch(tmp_path):
+    from sp_coupler_amd import spio
+    from sp_coupler_amd.driver import Coupler
+    gcm, les_models = models.make_models(3, nG=19, nL=160, seed=2)
+    path = str(tmp_path / "spifs.nc")
+    calls = []
+    w = spio.SpifsWriter(path, [m.grid_index for m in les_models], [0] * 3, [0] * 3, les_models[0].zf_cache, 19)
+    orig = w.write
+    w.write = lambda rows=None, **kw: (calls.append(sorted(kw)), orig(rows=rows, **kw))[1]
+    spcpl.writer = w
+    Coupler(gcm, les_models, cplsurf=True, write=True).run(2)
+    w.close()
+    assert len(calls) == 2 * 3                 # per step: forward state+forcings, surface block, backward block
+    c = spio.read_column(path, 2)
+    assert c["Time"].tolist() == [900.0, 1800.0] and numpy.isfinite(c["f_T"]).all() and numpy.isfinite(c["t"]).all()

@@ -269,8 +269,14 @@ constexpr int cfloor_pow2(int n) { int p = 1; while (p * 2 <= n) p *= 2; return 
 // NG / NL != 0: level counts fixed at compile time and contiguous columns (pitch == level count): the
 // flat-index divisions become multiply-shifts, the searches unroll, no pitch registers (hot geometries
 // 91<->160, 137<->512, 19<->160); NG == NL == 0: everything from DimsP at run time.
+#ifndef SPC_K1_WAVES
+#define SPC_K1_WAVES 1
+#endif
+#ifndef SPC_K3_WAVES
+#define SPC_K3_WAVES 1
+#endif
 template <typename T, bool FULL, int NG, int NL, int WT>
-__global__ __launch_bounds__(BLOCK) void k_forward(const FwdP<T, FULL> p)
+__global__ __launch_bounds__(BLOCK, SPC_K1_WAVES) void k_forward(const FwdP<T, FULL> p)
 {
     const DimsP &d = p.d;
     const int nG = NG ? NG : d.nG, nL = NL ? NL : d.nL, cb = d.cb;
@@ -447,7 +453,7 @@ template <typename T> __device__ __forceinline__ GcmIn<T> load_gcm(const BwdP<T>
     return r;
 }
 
-template <typename T, int NG, int NL, int WT> __global__ __launch_bounds__(BLOCK) void k_backward(const BwdP<T> p)
+template <typename T, int NG, int NL, int WT> __global__ __launch_bounds__(BLOCK, SPC_K3_WAVES) void k_backward(const BwdP<T> p)
 {
     const DimsP &d = p.d;
     const int nG = NG ? NG : d.nG, nL = NL ? NL : d.nL, cb = d.cb, tid = threadIdx.x;

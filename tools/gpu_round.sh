@@ -18,3 +18,5 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_ou
 echo "pmc write exit=$?"
 cd $R && python tools/pmc_summary.py gpurun_out/pmc_fetch_$TAG gpurun_out/pmc_write_$TAG 1024 268435456 gpurun_out/traffic_$TAG.json > $R/gpurun_out/pmc_summary_$TAG.log 2>&1
 tail -30 $R/gpurun_out/pmc_summary_$TAG.log
+timeout -k 10 300 python tools/kbench.py --sizes 1024,2048,4096,8192,16384,35718,348528 --cbs 0 > $R/gpurun_out/kbench_sizes_$TAG.log 2>&1
+grep n= $R/gpurun_out/kbench_sizes_$TAG.log

@@ -196,6 +196,9 @@ static double np_pairwise_sum(const double *a, int64_t n)
     }
 }
 
+/* exported for tests/test_properties.py */
+double oracle_pairwise_sum(const double *a, int64_t n) { return np_pairwise_sum(a, n); }
+
 /* sputils.integral with weights (splib/sputils.py:94-161); *ok = 0 where the reference returns None */
 static double integral_w(double a, double b, const double *z, int64_t nz, const double *q, const double *w,
                          double *tmp, int *ok)

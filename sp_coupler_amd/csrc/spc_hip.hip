@@ -187,7 +187,7 @@ template <typename T> __device__ __forceinline__ T interp_at(const Bracket<T> &b
 // ---- kernel parameter blocks (typed copies of the C structs) ------------------------------------
 struct DimsP {
     int64_t n_cols, pitchG, pitchGh, pitchL;
-    int nG, nL, cb, p2G, p2L, shared_grid;
+    int nG, nL, cb, p2G, p2L, shared_grid, xcd_remap;
 };
 
 struct Empty {};
@@ -228,6 +228,27 @@ template <typename T> struct DiagP {
 };
 
 extern __shared__ __align__(16) unsigned char spc_smem[];
+
+// XCD-aware workgroup -> column-slab mapping.  The dispatcher deals workgroups round-robin over the 8
+// XCDs (b and b+8 share one, each XCD has its own L2), while rows of 91 doubles (728 B) are not 128-B
+// aligned: with the identity mapping the cache line shared by two neighbouring slabs is fetched by two
+// different XCDs.  Giving each XCD a CONTIGUOUS range of slabs keeps those lines in one L2.  Speed only,
+// never correctness (every slab is still processed exactly once).  Used for slabs of <= 2 columns, where
+// slab boundaries are frequent (K3: +4-6 % at 35k-349k columns; 8-column slabs of K1: -1.5 %, so not there).
+// -DSPC_XCD_REMAP=0 disables it altogether (A/B).
+#ifndef SPC_XCD_REMAP
+#define SPC_XCD_REMAP 1
+#endif
+__device__ __forceinline__ unsigned slab_index(int remap)
+{
+#if SPC_XCD_REMAP
+    if (remap) {
+        const unsigned b = blockIdx.x, nb = gridDim.x, x = b & 7u, j = b >> 3, q = nb >> 3, r = nb & 7u;
+        return x * q + (x < r ? x : r) + j;
+    }
+#endif
+    return blockIdx.x;
+}
 
 // Diagnostic build only (-DSPC_STAMPS, tools/stamps.py): thread 0 of each workgroup drains its memory
 // counters and writes the 100 MHz wall clock at phase boundaries into a buffer no kernel code reads.
@@ -283,7 +304,7 @@ __global__ __launch_bounds__(BLOCK, SPC_K1_WAVES) void k_forward(const FwdP<T, F
     const int64_t pitchG = NG ? NG : d.pitchG, pitchGh = NG ? NG + 1 : d.pitchGh, pitchL = NL ? NL : d.pitchL;
     const int p2G = NG ? cfloor_pow2(NG ? NG : 1) : d.p2G;
     const int tid = threadIdx.x;
-    const int64_t col0 = (int64_t)blockIdx.x * cb;
+    const int64_t col0 = (int64_t)slab_index(d.xcd_remap) * cb;
     const int ncol = (int)((d.n_cols - col0) < cb ? (d.n_cols - col0) : cb);
     T *const lds = reinterpret_cast<T *>(spc_smem);
     T *const lzh = lds + (size_t)cb * 6 * nG;
@@ -419,7 +440,7 @@ template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_cloud_idx(const DimsP d, const T *zh_, const T *Zh_, int32_t *idx)
 {
     const int nG = d.nG, nL = d.nL, cb = d.cb, tid = threadIdx.x;
-    const int64_t col0 = (int64_t)blockIdx.x * cb;
+    const int64_t col0 = (int64_t)slab_index(d.xcd_remap) * cb;
     const int ncol = (int)((d.n_cols - col0) < cb ? (d.n_cols - col0) : cb);
     T *const lzh = reinterpret_cast<T *>(spc_smem);
     const int nz = d.shared_grid ? nL : ncol * nL;
@@ -459,7 +480,7 @@ template <typename T, int NG, int NL, int WT> __global__ __launch_bounds__(BLOCK
     const int nG = NG ? NG : d.nG, nL = NL ? NL : d.nL, cb = d.cb, tid = threadIdx.x;
     const int64_t pitchG = NG ? NG : d.pitchG, pitchGh = NG ? NG + 1 : d.pitchGh, pitchL = NL ? NL : d.pitchL;
     const int p2L = NL ? cfloor_pow2(NL ? NL : 1) : d.p2L;
-    const int64_t col0 = (int64_t)blockIdx.x * cb;
+    const int64_t col0 = (int64_t)slab_index(d.xcd_remap) * cb;
     const int ncol = (int)((d.n_cols - col0) < cb ? (d.n_cols - col0) : cb);
     const size_t per_col = (size_t)6 * nL + nG;
     T *const lds = reinterpret_cast<T *>(spc_smem);
@@ -605,7 +626,7 @@ template <typename T> __global__ __launch_bounds__(BLOCK) void k_backward_cons(c
 {
     const DimsP &d = p.d;
     const int nG = d.nG, nL = d.nL, cb = d.cb, tid = threadIdx.x;
-    const int64_t col0 = (int64_t)blockIdx.x * cb;
+    const int64_t col0 = (int64_t)slab_index(d.xcd_remap) * cb;
     const int ncol = (int)((d.n_cols - col0) < cb ? (d.n_cols - col0) : cb);
     const size_t per_col = (size_t)7 * nL + nG + (nG + 1);
     T *const lds = reinterpret_cast<T *>(spc_smem);
@@ -716,7 +737,7 @@ template <typename T> __global__ __launch_bounds__(BLOCK) void k_diag(const Diag
 {
     const DimsP &d = p.d;
     const int nG = d.nG, nL = d.nL, cb = d.cb, tid = threadIdx.x;
-    const int64_t col0 = (int64_t)blockIdx.x * cb;
+    const int64_t col0 = (int64_t)slab_index(d.xcd_remap) * cb;
     const int ncol = (int)((d.n_cols - col0) < cb ? (d.n_cols - col0) : cb);
     T *const lds = reinterpret_cast<T *>(spc_smem);
     const T cc = K<T>::rv / K<T>::rd - T(1);                                           // spcpl.py:175
@@ -901,6 +922,7 @@ DimsP make_dims(const spc_dims *d, int cb)
     p.n_cols = d->n_cols; p.pitchG = d->pitchG; p.pitchGh = d->pitchGh; p.pitchL = d->pitchL;
     p.nG = d->nG; p.nL = d->nL; p.cb = cb; p.p2G = floor_pow2(d->nG); p.p2L = floor_pow2(d->nL);
     p.shared_grid = d->les_grid_shared != 0;
+    p.xcd_remap = cb <= 2;   // measured: +4-6 % for 1-2 column slabs (K3), -1.5 % for 8-column slabs (K1)
     return p;
 }
 

@@ -242,6 +242,23 @@ def main():
             res[name] = e0.elapsed_time(e1) * 1e3 / ke
         k1_us, k3_us = res["k1"], res["k3"]
 
+    # measured device-to-device copy rate of this box (16 B/lane streaming copy, 256 MiB, read + write bytes):
+    # the practical HBM ceiling reported next to the 8 TB/s spec peak
+    copy_gbs = None
+    if not args.no_kernel_events:
+        src = torch.empty(1 << 28, dtype=torch.uint8, device=eng.device)
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            eng.stream_copy(dst, src, stream)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record(stream)
+        for _ in range(10):
+            eng.stream_copy(dst, src, stream)
+        c1.record(stream)
+        torch.cuda.synchronize()
+        copy_gbs = 2.0 * src.numel() * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        del src, dst
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -273,6 +290,7 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": "k_forward<double,false> (K1+K2 fused)", "achieved": ach,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                            "algorithmic_bytes_per_launch": ab["k1_launch"] * n_cols, "avg_launch_us": k1_us,
+                           "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": (ach / copy_gbs) if copy_gbs else None,
                            "timing": dict(kdiag, method="HIP events around %d back-to-back launches of the kernel "
                                           "alone on the launch stream" % min(args.steps, 400)),
                            "backward": {"kernel": "k_backward<double> (K3)", "avg_launch_us": k3_us,

@@ -891,8 +891,9 @@ template <typename KernelT> int pick_cb(const spc_dims *d, int pass, bool with_i
     int best = 1, best_nb = -1;
     for (int i = 3; i >= 0; --i) {                                                      // rule 2
         cb = 1 << i;
-        const bool two_rounds = (d->n_cols + cb - 1) / cb >= (int64_t)2 * 256 * nb[i];
-        if (nb[i] > best_nb && (two_rounds || i == 0)) { best_nb = nb[i]; best = cb; }
+        const int64_t rounds_x256 = nb[i] ? (d->n_cols + cb - 1) / cb / nb[i] : 0;   // rounds of workgroups x 256
+        const bool enough = rounds_x256 >= (cb == 8 ? 8 : 2) * 256;   // measured: 8-column slabs pay off from ~8 rounds
+        if (nb[i] > best_nb && (enough || i == 0)) { best_nb = nb[i]; best = cb; }
     }
     return best;
 }

@@ -283,7 +283,9 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_forward_bytes_per_launch")
+                tj = json.load(open(tpath))     # PMC passes of tools/gpu_round.sh (separate --pmc runs, calibrated)
+                if tj.get("n_cols") == n_cols and (nG, nL) == (91, 160):
+                    traffic = tj.get("k_forward_bytes_per_launch")
             except Exception:
                 traffic = None
         ach = ab["k1_launch"] * n_cols / (k1_us * 1e-6) / 1e9

@@ -184,6 +184,64 @@ template <typename T> __device__ __forceinline__ T interp_at(const Bracket<T> &b
     return lerp_np(b.x, b.x0, b.x1, fp[b.j], fp[b.j + 1]);
 }
 
+// ---- branch-light form used by the hot kernels -------------------------------------------------
+// Every case of numpy.interp expressed as ONE predicated code path, so that the 5 (K1) / 7 (K3)
+// independent slope divisions of a level sit in one basic block and interleave:
+//   take : the result is the sample fp[j0] itself (x outside [xp[0], xp[n-1]], x == xp[j], n == 1)
+//   nanx : the result is x itself (NaN x, n > 1)
+//   else : numpy's slope form between samples j0 and j1 = j0 + 1
+// For take / nanx lanes (x0, x1) = (0, 1) and j1 == j0, so the (discarded) slope arithmetic stays finite.
+template <typename T> struct Br {
+    int j0, j1;
+    bool take, nanx;
+    T x, x0, x1;
+};
+
+template <typename T> __device__ __forceinline__ Br<T> bracket2(const T *xp, int n, int p2, T x)
+{
+    Br<T> b;
+    const int j = upper_count(xp, n, p2, x) - 1;           // NaN x: every comparison false -> j = -1
+    const bool below = j < 0, above = j >= n - 1;
+    const int jmax = n >= 2 ? n - 2 : 0;
+    const int jc = j < 0 ? 0 : (j > jmax ? jmax : j);
+    const T x0 = xp[jc], x1 = xp[jc + 1 < n ? jc + 1 : n - 1];
+    b.take = (n == 1) | below | above | (x0 == x);
+    b.nanx = (x != x) & (n != 1);
+    b.j0 = above ? n - 1 : jc;
+    b.j1 = b.take ? b.j0 : jc + 1;
+    b.x = x;
+    b.x0 = b.take ? T(0) : x0;
+    b.x1 = b.take ? T(1) : x1;
+    return b;
+}
+
+// r[k] = numpy.interp result of field k given the samples f0[k] = fp_k[j0], f1[k] = fp_k[j1]
+template <int NF, typename T> __device__ __forceinline__ void interp_fields(const Br<T> &b, const T (&f0)[NF], const T (&f1)[NF], T (&r)[NF])
+{
+    const T dx = b.x1 - b.x0, t0 = b.x - b.x0;
+    T slope[NF];
+    bool any_nan = false;
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+        slope[k] = (f1[k] - f0[k]) / dx;
+        r[k] = slope[k] * t0 + f0[k];
+        any_nan |= (r[k] != r[k]);
+    }
+    if (any_nan & !b.take & !b.nanx) {   // numpy's NaN fallbacks: rare, one masked block for all fields
+        const T t1 = b.x - b.x1;
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+            if (r[k] != r[k]) {
+                T q = slope[k] * t1 + f1[k];
+                if (q != q && f0[k] == f1[k]) q = f0[k];
+                r[k] = q;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NF; ++k) r[k] = b.nanx ? b.x : (b.take ? f0[k] : r[k]);
+}
+
 // ---- kernel parameter blocks (typed copies of the C structs) ------------------------------------
 struct DimsP {
     int64_t n_cols, pitchG, pitchGh, pitchL;
@@ -390,12 +448,15 @@ __global__ __launch_bounds__(BLOCK, SPC_K1_WAVES) void k_forward(const FwdP<T, F
             const int64_t col = col0 + c, o = col * pitchL + l;
             const T *const s = lds + (size_t)c * 6 * nG;
             const LesIn<T> in = (e == tid) ? pre2 : load_les<FwdP<T, FULL>, T>(p, l, o);
-            const Bracket<T> b = bracket(s, nG, p2G, in.h);
-            const T thl = interp_at(b, s + nG);                                       // spcpl.py:224
-            const T qt = interp_at(b, s + 2 * nG);                                    // spcpl.py:225
-            const T ql = interp_at(b, s + 3 * nG);                                    // spcpl.py:226
-            const T u = interp_at(b, s + 4 * nG);                                     // spcpl.py:227
-            const T v = interp_at(b, s + 5 * nG);                                     // spcpl.py:228
+            const Br<T> b = bracket2(s, nG, p2G, in.h);
+            T f0[5], f1[5], r[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                f0[k] = s[(k + 1) * nG + b.j0];
+                f1[k] = s[(k + 1) * nG + b.j1];
+            }
+            interp_fields<5>(b, f0, f1, r);
+            const T thl = r[0], qt = r[1], ql = r[2], u = r[3], v = r[4];               // spcpl.py:224-228
             stg<WT>(&p.f_u[o], p.factor * (u - in.ud) / p.dt);               // spcpl.py:328
             stg<WT>(&p.f_v[o], p.factor * (v - in.vd) / p.dt);               // spcpl.py:329
             stg<WT>(&p.f_thl[o], p.factor * (thl - in.thld) / p.dt);         // spcpl.py:330
@@ -527,6 +588,8 @@ template <typename T, int NG, int NL, int WT> __global__ __launch_bounds__(BLOCK
         const GcmIn<T> in = (e == tid) ? pre : load_gcm(p, g, cg + (nG - 1 - k));
         const T x = Zf[k];
         const int start_index = ss_left_neg(Zf, nG, h[nL - 1]);                        // spcpl.py:498
+        // (the branch-light interp_fields<7> form was measured here too: no gain at 1024 columns and -12 % at
+        //  >= 35k columns, because interleaving 7 division chains costs 118 VGPRs and a third of the occupancy)
         const Bracket<T> b = bracket(h, nL, p2L, x);
         T t_i, qt_i, ql_i, qlw_i, qli_i, u_i, v_i;
         if (b.mode == 0) {

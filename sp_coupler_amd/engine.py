@@ -267,8 +267,8 @@ class Engine:
         res = {}
         for name in ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A"):
             t = out.get(name)
-            if t is None:
-                t = self.empty(n, nG)
+            if t is None:   # outputs share the column pitch of the GCM full-level inputs
+                t = torch.empty(n, pitchG or nG, device=self.device, dtype=self.dtype)[:, :nG]
             ptr, pitchG = ck.mat("out[%s]" % name, t, n, nG, pitchG)
             setattr(a, name, ptr)
             res[name] = t
@@ -299,10 +299,10 @@ class Engine:
         a.Zghalf, pitchGh = ck.mat("gcm[Zghalf]", gcm["Zghalf"], n, nG + 1, pitchGh)
         res = {}
         for name in ("Tv", "THL", "QT", "Zf"):
-            res[name] = self.empty(n, nG)
+            res[name] = torch.empty(n, pitchG or nG, device=self.device, dtype=self.dtype)[:, :nG]
             ptr, pitchG = ck.mat(name, res[name], n, nG, pitchG)
             setattr(a, name, ptr)
-        res["Zh"] = self.empty(n, nG + 1)
+        res["Zh"] = torch.empty(n, pitchGh or nG + 1, device=self.device, dtype=self.dtype)[:, :nG + 1]
         a.Zh, pitchGh = ck.mat("Zh", res["Zh"], n, nG + 1, pitchGh)
         nL, shared = 1, 1
         if zf is not None and prof is not None:
@@ -312,7 +312,7 @@ class Engine:
                 setattr(a, field, ptr)
             a.zf, shared = self._grid(ck, "zf", zf, n, nL, pitchL)
             for name in ("pf", "t", "ql_water"):
-                res[name] = self.empty(n, nL)
+                res[name] = torch.empty(n, pitchL or nL, device=self.device, dtype=self.dtype)[:, :nL]
                 ptr, pitchL = ck.mat(name, res[name], n, nL, pitchL)
                 setattr(a, name, ptr)
         dims = _abi.Dims(n, nG, nL, pitchG or nG, pitchGh or nG + 1, pitchL or nL, shared, int(cols_per_block))

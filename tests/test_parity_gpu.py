@@ -277,3 +277,39 @@ def test_tall_les_columns_use_large_lds_and_too_tall_is_refused(eng):
     with pytest.raises(_abi.SpcError) as e:
         eng.backward(g, torch.from_numpy(zf).to(eng.device), p, 1.0, DT)
     assert e.value.code == _abi.SPC_ERR_UNSUPPORTED
+
+
+def test_random_geometries_pitches_and_slab_sizes(eng):
+    """Fuzz of the run-time-geometry kernels: random level counts, column counts, slab sizes, padded pitches,
+    shared / per-column LES grids -- every launch bit-checked against the plain-C oracle."""
+    rng = numpy.random.default_rng(2026)
+    for trial in range(40):
+        nG = int(rng.integers(1, 200))
+        nL = int(rng.integers(1, 600))
+        n = int(rng.integers(1, 260))
+        cb = int(rng.choice([0, 1, 2, 3, 5, 8]))
+        per_col = bool(rng.integers(0, 2)) and nL > 1
+        pad = int(rng.choice([0, 0, 1, 7]))
+        gcm, zf, zh, prof = synthetic.make_batch(n, nG, nL, seed=7000 + trial, per_column_grid=per_col)
+
+        def dev(v):
+            t = torch.from_numpy(numpy.ascontiguousarray(v)).to(eng.device)
+            if pad and t.dim() == 2:
+                buf = torch.full((t.shape[0], t.shape[1] + pad), float("nan"), device=eng.device, dtype=t.dtype)
+                buf[:, :t.shape[1]] = t
+                return buf[:, :t.shape[1]]
+            return t
+        g = {k: dev(v) for k, v in gcm.items()}
+        p = {k: dev(v) for k, v in prof.items()}
+        zf_d, zh_d = dev(zf), dev(zh)
+        fwd = eng.forward(g, zf_d, p, FACTOR, DT, zh=zh_d, want_profiles=True, couple_surface=True, cols_per_block=cb)
+        bwd = eng.backward(g, zf_d, p, FACTOR, DT, Zf=fwd["Zf"] if trial % 2 else None, cols_per_block=cb)
+        torch.cuda.synchronize()
+        ref_f = oracle_c.forward(gcm, zf, zh, prof, FACTOR, DT)
+        ref_b = oracle_c.backward(gcm, ref_f["Zf"], zf, prof, FACTOR, DT)
+        tag = "trial %d nG=%d nL=%d n=%d cb=%d per_col=%s pad=%d" % (trial, nG, nL, n, cb, per_col, pad)
+        try:
+            check_forward({k: host(v) for k, v in fwd.items()}, ref_f, numpy.abs(ref_f["thl"]).max())
+            check_backward({k: host(v) for k, v in bwd.items()}, ref_b)
+        except AssertionError as e:
+            raise AssertionError(tag + ": " + str(e))

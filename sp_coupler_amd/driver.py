@@ -96,7 +96,7 @@ class Coupler:
     def step_spinup(self, spinup_length, les_spinup_forcing_factor=1.0):
         if not self.les_models:
             return
-        if spcpl.current_batch() is None:
+        if any(getattr(les, "_spc_batch", None) is None for les in self.les_models):   # splib.py:196 gathered at init
             spcpl.gather_gcm_data(self.gcm, self.les_models, self.cplsurf, write=self.write)
         t_les = self.les_models[0].get_model_time()
         pool = RequestsPool()
@@ -108,6 +108,8 @@ class Coupler:
                 pool.add_request(r)
         pool.waitall()
         _, self.profiles = self.step_les_models(t_les + spinup_length, offset=0)
+        if self.write and spcpl.writer is not None:                           # splib/splib.py:388-391
+            spcpl.write_les_profiles_batched(self.les_models)
         self.firststep = False
 
     def run(self, nsteps):

@@ -10,6 +10,7 @@ Same function names, argument meaning and return values as the reference module,
     get_les_profiles(les, asynchronous) -> dict                                                spcpl.py:747
     get_cloud_fraction(les)                                                                    spcpl.py:22
     set_gcm_tendencies(gcm, les, profile, dt_gcm, factor=1, write=True, conservative=False)    spcpl.py:388
+    write_les_profiles(les) / set_les_state(les, u, v, thl, qt, ps=None)                       spcpl.py:574/274
     convert_surface_fluxes(les) / output_column_conversion(profile)                            spcpl.py:136/251
 
 What differs is WHERE the arithmetic runs: ``gather_gcm_data`` packs every SP column into
@@ -487,6 +488,42 @@ def set_gcm_tendencies_batched(gcm, les_models, profiles, dt_gcm, factor=1, writ
         batch.profiles[id(les)] = profiles[les]
     for les in les_models:
         set_gcm_tendencies(gcm, les, None, dt_gcm, factor, write, conservative)
+
+
+# ---------------------------------------------------------------------------------------------
+# spinup diagnostics: splib/spcpl.py:574-609
+# ---------------------------------------------------------------------------------------------
+def write_les_profiles_batched(les_models):
+    """Fetch the LES slab means of every column and write them to spifs (used during spinup,
+    splib/splib.py:390): u, v, presf, qt, ql, ql_ice, ql_water, thl, t (from K5 with the GCM pressures,
+    spcpl.py:593-594), t_, qr.  One getter round per column (RPC, as in the reference), ONE kernel launch
+    and one write per variable for all columns.  Returns the dict of host arrays it wrote."""
+    if not les_models:
+        return {}
+    batch = _batch_of(les_models[0])
+    src = lambda m: {"U": m.get_profile_U(), "V": m.get_profile_V(), "presf": m.get_presf(),      # noqa: E731
+                     "THL": m.get_profile_THL(), "QT": m.get_profile_QT(), "QL": m.get_profile_QL(),
+                     "QL_ice": m.get_profile_QL_ice(), "QR": m.get_profile_QR(), "T": m.get_profile_T()}
+    prof = batch.stack_profiles(("U", "V", "presf", "THL", "QT", "QL", "QL_ice", "QR", "T"), src)
+    d = batch.engine.diagnostics(batch.gcm, batch.zf, prof)                                  # K5: t, ql_water
+    h = lambda t: t.cpu().numpy()                # noqa: E731
+    out = dict(u=h(prof["U"]), v=h(prof["V"]), presf=h(prof["presf"]), qt=h(prof["QT"]), ql=h(prof["QL"]),
+               ql_ice=h(prof["QL_ice"]), ql_water=h(d["ql_water"]), thl=h(prof["THL"]), t=h(d["t"]), t_=h(prof["T"]),
+               qr=h(prof["QR"]))
+    if writer is not None:
+        writer.write(**out)
+    return out
+
+
+def write_les_profiles(les):
+    """splib/spcpl.py:574-609 for one column (computes the whole batch on the first call of a step)."""
+    batch = _batch_of(les)
+    key = ("wlp", batch.profile_generation, id(batch.fwd))
+    if getattr(batch, "wlp_key", None) != key:
+        batch.wlp = write_les_profiles_batched(batch.les_models)
+        batch.wlp_key = key
+    i = batch.index_of(les)
+    return {k: v[i] for k, v in batch.wlp.items()}
 
 
 # ---------------------------------------------------------------------------------------------

@@ -107,3 +107,25 @@ def test_spifs_hook_writes_once_per_launch(tmp_path):
     assert len(calls) == 2 * 3                 # per step: forward state+forcings, surface block, backward block
     c = spio.read_column(path, 2)
     assert c["Time"].tolist() == [900.0, 1800.0] and numpy.isfinite(c["f_T"]).all() and numpy.isfinite(c["t"]).all()
+
+
+def test_spinup_steps_and_write_les_profiles(tmp_path):
+    """step_spinup (splib/splib.py:355-402): forcings with dt = spinup length, LES stepped, slab means written"""
+    from sp_coupler_amd import spio
+    from sp_coupler_amd.driver import Coupler
+    gcm, les_models = models.make_models(3, nG=19, nL=160, seed=12)
+    path = str(tmp_path / "spifs.nc")
+    spcpl.writer = spio.SpifsWriter(path, [m.grid_index for m in les_models], [0] * 3, [0] * 3, les_models[0].zf_cache, 19)
+    cpl = Coupler(gcm, les_models, write=True)
+    thl0 = les_models[0].p["THL"].copy()
+    for s_ in range(2):
+        spcpl.writer.update_time(100.0 * (s_ + 1))
+        cpl.step_spinup(100.0, les_spinup_forcing_factor=0.5)
+    spcpl.writer.close()
+    spcpl.writer = None
+    assert les_models[0].model_time == 200.0 and not numpy.array_equal(les_models[0].p["THL"], thl0)
+    c = spio.read_column(path, 1)
+    assert numpy.array_equal(c["thl"][1], les_models[1].p["THL"].astype(numpy.float32))
+    assert numpy.isfinite(c["t"]).all() and numpy.isfinite(c["ql_water"]).all()
+    one = spcpl.write_les_profiles(les_models[2])
+    assert one["u"].shape == (160,) and numpy.array_equal(one["thl"], les_models[2].p["THL"])

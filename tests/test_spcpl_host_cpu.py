@@ -129,3 +129,34 @@ def test_spinup_steps_and_write_les_profiles(tmp_path):
     assert numpy.isfinite(c["t"]).all() and numpy.isfinite(c["ql_water"]).all()
     one = spcpl.write_les_profiles(les_models[2])
     assert one["u"].shape == (160,) and numpy.array_equal(one["thl"], les_models[2].p["THL"])
+
+
+def test_extra_output_columns_are_converted_and_written(tmp_path):
+    """gather_gcm_data's extra output columns (spcpl.py:89-129): output_column_conversion + surface fluxes of
+    columns WITHOUT an LES, written into their rows of the spifs file."""
+    from oracle import spcpl_oracle as orc
+    from sp_coupler_amd import spio
+    gcm, les_models = models.make_models(2, npoints=8, nG=19, nL=160, seed=5)
+    extra = [5, 6]
+    path = str(tmp_path / "spifs.nc")
+    idxs = [m.grid_index for m in les_models] + extra
+    spcpl.writer = spio.SpifsWriter(path, idxs, [0] * 4, [0] * 4, les_models[0].zf_cache, 19)
+    spcpl.writer_rows = {5: 2, 6: 3}
+    spcpl.writer.update_time(900.0)
+    batch = spcpl.gather_gcm_data(gcm, les_models, True, extra, write=True)
+    spcpl.writer.close()
+    spcpl.writer, spcpl.writer_rows = None, {}
+    assert batch.n == 2 and batch.gcm["T"].shape == (2, 19) and batch.gcm_host["T"].shape == (4, 19)
+    c = spio.read_column(path, 3)                                     # GCM grid index 6
+    col = {"T": gcm.state["T"][6], "SH": gcm.state["SH"][6], "QL": gcm.state["QL"][6], "QI": gcm.state["QI"][6],
+           "Pf": gcm.state["Pfull"][6], "Ph": gcm.state["Phalf"][6], "Zgfull": gcm.state["Zgfull"][6],
+           "Zghalf": gcm.state["Zghalf"][6]}
+    orc.output_column_conversion(col)
+    for k in ("Tv", "THL", "QT", "Zf", "Zh", "Ph"):
+        assert numpy.array_equal(c[k][0], col[k].astype(numpy.float32)), k
+    assert c["Psurf"][0] == numpy.float32(col["Psurf"])
+    sf = {"Phalf": gcm.state["Phalf"][6], "T": gcm.state["T"][6]}
+    sf.update({k: gcm.state[k][6] for k in ("Z0M", "Z0H", "QLflux", "QIflux", "SHflux", "TSflux")})
+    z0m, z0h, wthl, wqt = orc.convert_surface_fluxes(sf)
+    assert c["wthl"][0] == numpy.float32(wthl) and c["wqt"][0] == numpy.float32(wqt) and c["z0m"][0] == numpy.float32(z0m)
+    assert numpy.isnan(spio.read_column(path, 0)["Tv"][0]).all()       # SP columns were not written by gather itself

@@ -147,7 +147,17 @@ def main():
     if world > 1:
         import torch.distributed as dist
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+                probe = torch.zeros(1, device="cuda:%d" % local)
+                dist.all_reduce(probe)                      # fail here, not in the timed region
+                torch.cuda.synchronize()
+            except Exception as e:                          # the data path needs no collective: gloo is enough
+                print("bench.py: RCCL unavailable (%r), using gloo for barrier/max" % (e,), file=sys.stderr)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                args.backend = "gloo"
+                dist.init_process_group("gloo")
         else:
             dist.init_process_group(args.backend)
 

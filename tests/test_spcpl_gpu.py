@@ -211,3 +211,43 @@ def test_surface_fluxes_dict_form_and_set_les_state():
     numpy.random.seed(42)
     noise = 0.5 * numpy.random.uniform(-1., 1., (8, 8, 160))
     assert numpy.allclose(les_models[0].p["U"], (noise + u).mean(axis=(0, 1)), rtol=0, atol=1e-12)
+
+
+def test_get_cloudfraction_like_the_reference_test():
+    """The reference's own spcpl test (splib/test/spcpl_test.py:10-16), through the drop-in API: a dummy LES with
+    spdummy's grid (k=20, dz=200: zf=k*dz, zh=(k+0.5)*dz, spdummy.py:185-222) and cloud-fraction profile
+    A=0.5+0.2cos(6 zf/(dz k)) clipped to 0..k-1 (spdummy.py:261-262,319-321); gcm_Zh=[1e5,1e3,100,10,1,0]."""
+    from sp_coupler_amd import spcpl
+    from tests.test_parity_gpu import _ulp_search
+    k, dz, grav = 20, 200.0, 9.81
+
+    class DummyLes:
+        grid_index = 1
+        zf_cache = numpy.arange(k) * dz
+        zh_cache = (numpy.arange(k) + 0.5) * dz
+
+        def get_cloudfraction(self, i):
+            indices = numpy.clip(i, 0, k - 1)
+            return (0.5 + 0.2 * numpy.cos(6. * self.zf_cache / (dz * k)))[indices]
+
+    class DummyGcm:
+        def get_profile_fields(self, var, cols):
+            Zh = numpy.array([100000., 1000., 100., 10., 1., 0.])
+            if var == "Zghalf":
+                return numpy.array([[_ulp_search(z, grav) if z else 0.0 for z in Zh]])
+            if var == "Zgfull":
+                return numpy.array([0.5 * (Zh[:-1] + Zh[1:]) * grav])
+            if var == "Phalf":
+                return numpy.array([[0.0, 2e4, 5e4, 8e4, 9.5e4, 1e5]])
+            if var in ("Pfull", "T"):
+                return numpy.array([[1e4, 3.5e4, 6.5e4, 8.7e4, 9.7e4]]) if var == "Pfull" else numpy.full((1, 5), 280.0)
+            return numpy.zeros((1, 5))
+
+    les = DummyLes()
+    spcpl.gather_gcm_data(DummyGcm(), [les], False, write=False)
+    A = spcpl.get_cloud_fraction(les)
+    assert numpy.array_equal(les.gcm_Zh, [100000., 1000., 100., 10., 1., 0.])
+    assert spcpl.cloud_fraction_indices(les).tolist() == [0, 0, 1, 5, 20]
+    tolerance = 1.e-10                                                         # spcpl_test.py:7
+    assert abs(A[0] - (0.5 + 0.2 * numpy.cos(6. * (1. - k) / k))) < tolerance    # spcpl_test.py:15
+    assert abs(A[-1] - (0.5 + 0.2)) < tolerance                                # spcpl_test.py:16

@@ -282,8 +282,9 @@ def test_tall_les_columns_use_large_lds_and_too_tall_is_refused(eng):
 def test_random_geometries_pitches_and_slab_sizes(eng):
     """Fuzz of the run-time-geometry kernels: random level counts, column counts, slab sizes, padded pitches,
     shared / per-column LES grids -- every launch bit-checked against the plain-C oracle."""
-    rng = numpy.random.default_rng(2026)
-    for trial in range(40):
+    import os
+    rng = numpy.random.default_rng(int(os.environ.get("SPC_FUZZ_SEED", "2026")))
+    for trial in range(int(os.environ.get("SPC_FUZZ_TRIALS", "40"))):     # soak: SPC_FUZZ_TRIALS=500 SPC_FUZZ_SEED=n
         nG = int(rng.integers(1, 200))
         nL = int(rng.integers(1, 600))
         n = int(rng.integers(1, 260))

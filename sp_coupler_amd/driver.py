@@ -29,6 +29,12 @@ class Coupler:
             if not hasattr(les, "zf_cache"):
                 les.zh_cache, les.zf_cache = les.get_zh(), les.get_zf()    # splib/splib.py:152-153
 
+    def initialize_output(self, les_spinup_steps=1):
+        """splib.initialize (splib/splib.py:192-193): the spifs record the FIRST step writes into is opened at
+        initialisation with the spin-up time stamp; ``step`` appends a record only from the second step on."""
+        if self.write and spcpl.writer is not None:
+            spcpl.writer.update_time(self.les_spinup / max(1, les_spinup_steps))
+
     # splib/splib.py:554-594 (async branch): evolve every LES, then fetch its slab means
     def step_les_models(self, model_time, offset=0):
         pool = RequestsPool()
@@ -53,8 +59,11 @@ class Coupler:
         delta_t = gcm.get_timestep()
         starttime = time.time()
         w1 = -time.time()
-        if self.write and spcpl.writer is not None:                           # spio.update_time, splib.py:287-288
-            spcpl.writer.update_time(t + self.les_spinup + delta_t)
+        if self.write and spcpl.writer is not None:
+            if not self.firststep:                                            # splib.py:287-288
+                spcpl.writer.update_time(t + self.les_spinup + delta_t)
+            elif spcpl.writer.step < 0:                                       # record 0 comes from initialize()
+                self.initialize_output()
         if gcm.first_half_step_done:
             gcm.first_half_step_done = False
         else:

@@ -21,9 +21,13 @@ BWD_LES = ("T", "QT", "QL", "QL_ice", "U", "V")                       # profile[
 _DTYPES = {torch.float64: "f64", torch.float32: "f32"}
 
 
-def _stream_ptr(stream):
+def _stream_ptr(stream, device=None):
+    """hipStream_t of ``stream`` (default: torch's current stream ON ``device``, not on whatever device
+    happens to be current) as a ctypes handle; a stream of another device is rejected."""
     if stream is None:
-        stream = torch.cuda.current_stream()
+        stream = torch.cuda.current_stream(device)
+    elif device is not None and stream.device != device:
+        raise ValueError("stream is on %s, engine is on %s" % (stream.device, device))
     return ctypes.c_void_p(stream.cuda_stream)
 
 
@@ -72,13 +76,16 @@ class _Plan:
 
     def launch(self, stream=None):
         """Enqueue the kernel on ``stream`` (default: torch's current stream). Returns outputs dict."""
-        rc = self._fn(self._dref, self._aref, _stream_ptr(stream))
+        eng = self.engine
+        with torch.cuda.device(eng.device):          # occupancy queries + launch on the engine's device
+            rc = self._fn(self._dref, self._aref, _stream_ptr(stream, eng.device))
         if rc:
-            _abi.check(self.engine.lib, rc)
+            _abi.check(eng.lib, rc)
         return self.outputs
 
     def launch_raw(self, stream_ptr):
-        """Same with a pre-fetched ``ctypes.c_void_p`` stream handle (hot loops)."""
+        """Same with a pre-fetched ``ctypes.c_void_p`` stream handle (hot loops). The caller guarantees that the
+        handle belongs to the engine's device and that this device is current (``torch.cuda.set_device``)."""
         rc = self._fn(self._dref, self._aref, stream_ptr)
         if rc:
             _abi.check(self.engine.lib, rc)
@@ -222,7 +229,8 @@ class Engine:
         pitchL = zh.stride(0) if (zh.dim() == 2 and n > 1) else nL
         idx = self.empty(n, nG, dtype=torch.int32)
         dims = _abi.Dims(n, nG, nL, nG, pitchGh, pitchL, shared, int(cols_per_block))
-        rc = self._idx(ctypes.byref(dims), zh_ptr, Zh_ptr, idx.data_ptr(), _stream_ptr(stream))
+        with torch.cuda.device(self.device):
+            rc = self._idx(ctypes.byref(dims), zh_ptr, Zh_ptr, idx.data_ptr(), _stream_ptr(stream, self.device))
         _abi.check(self.lib, rc)
         return idx
 
@@ -316,7 +324,8 @@ class Engine:
                 ptr, pitchL = ck.mat(name, res[name], n, nL, pitchL)
                 setattr(a, name, ptr)
         dims = _abi.Dims(n, nG, nL, pitchG or nG, pitchGh or nG + 1, pitchL or nL, shared, int(cols_per_block))
-        rc = self._diag(ctypes.byref(dims), ctypes.byref(a), _stream_ptr(stream))
+        with torch.cuda.device(self.device):
+            rc = self._diag(ctypes.byref(dims), ctypes.byref(a), _stream_ptr(stream, self.device))
         _abi.check(self.lib, rc)
         return res
 
@@ -329,7 +338,8 @@ class Engine:
                                                ("SHflux", SHflux), ("TSflux", TSflux))]
         wthl, wqt = self.empty(n), self.empty(n)
         fn = getattr(self.lib, "spc_surface_fluxes_" + _DTYPES[self.dtype])
-        rc = fn(n, *ptrs, wthl.data_ptr(), wqt.data_ptr(), _stream_ptr(stream))
+        with torch.cuda.device(self.device):
+            rc = fn(n, *ptrs, wthl.data_ptr(), wqt.data_ptr(), _stream_ptr(stream, self.device))
         _abi.check(self.lib, rc)
         return wthl, wqt
 
@@ -338,5 +348,6 @@ class Engine:
         nbytes = src.numel() * src.element_size()
         if dst.numel() * dst.element_size() != nbytes or not (src.is_contiguous() and dst.is_contiguous()):
             raise ValueError("stream_copy needs two contiguous tensors of equal byte size")
-        rc = self.lib.spc_stream_copy(dst.data_ptr(), src.data_ptr(), nbytes, _stream_ptr(stream))
+        with torch.cuda.device(self.device):
+            rc = self.lib.spc_stream_copy(dst.data_ptr(), src.data_ptr(), nbytes, _stream_ptr(stream, self.device))
         _abi.check(self.lib, rc)

@@ -63,13 +63,17 @@ class SpifsWriter:
 
     def write(self, rows=None, **arrays):
         """one slice write per variable for the whole batch: arrays[name] is [n x levels] or [n];
-        ``rows`` selects a subset of columns (extra output columns)."""
+        ``rows`` selects a subset of columns (extra output columns); an array with fewer rows than the file
+        has columns addresses rows 0..m-1 (the SP columns of a file that also holds extra output columns)."""
         with self.lock:
             for name, arr in arrays.items():
                 var = self.f.variables.get(name)
                 if var is None:
                     raise KeyError("Attempt to write profile to uninitialized variable %s" % name)   # spio.py:240
                 a = numpy.asarray(arr, dtype=numpy.float32)
+                if rows is None and a.ndim >= 1 and a.shape[0] < self.n:
+                    rows = numpy.arange(a.shape[0])      # the SP columns occupy the FIRST rows; extra output
+                                                         # columns (spcpl.py:89-129) follow and keep their values
                 if rows is None:
                     var[self.step] = a
                 else:

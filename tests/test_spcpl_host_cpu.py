@@ -106,7 +106,7 @@ def test_spifs_hook_writes_once_per_launch(tmp_path):
     w.close()
     assert len(calls) == 2 * 3                 # per step: forward state+forcings, surface block, backward block
     c = spio.read_column(path, 2)
-    assert c["Time"].tolist() == [900.0, 1800.0] and numpy.isfinite(c["f_T"]).all() and numpy.isfinite(c["t"]).all()
+    assert c["Time"].tolist() == [0.0, 1800.0] and numpy.isfinite(c["f_T"]).all() and numpy.isfinite(c["t"]).all()
 
 
 def test_spinup_steps_and_write_les_profiles(tmp_path):
@@ -160,3 +160,25 @@ def test_extra_output_columns_are_converted_and_written(tmp_path):
     z0m, z0h, wthl, wqt = orc.convert_surface_fluxes(sf)
     assert c["wthl"][0] == numpy.float32(wthl) and c["wqt"][0] == numpy.float32(wqt) and c["z0m"][0] == numpy.float32(z0m)
     assert numpy.isnan(spio.read_column(path, 0)["Tv"][0]).all()       # SP columns were not written by gather itself
+
+
+def test_full_steps_with_extra_output_columns_and_a_writer(tmp_path):
+    """Regression (round-1 advisor finding): a spifs file that ALSO holds extra output columns has n_les+extra
+    rows; the per-step writes of the SP columns must land in rows 0..n_les-1 and leave the extra columns'
+    rows (written by gather_gcm_data, spcpl.py:89-129) alone."""
+    from sp_coupler_amd import spio
+    from sp_coupler_amd.driver import Coupler
+    gcm, les_models = models.make_models(2, npoints=8, nG=19, nL=160, seed=5)
+    extra = [5, 6]
+    path = str(tmp_path / "spifs.nc")
+    idxs = [m.grid_index for m in les_models] + extra
+    spcpl.writer = spio.SpifsWriter(path, idxs, [0] * 4, [0] * 4, les_models[0].zf_cache, 19)
+    spcpl.writer_rows = {5: 2, 6: 3}
+    Coupler(gcm, les_models, cplsurf=True, write=True, output_column_indices=extra).run(2)
+    spcpl.writer.close()
+    spcpl.writer, spcpl.writer_rows = None, {}
+    sp, ex = spio.read_column(path, 1), spio.read_column(path, 3)
+    assert sp["Time"].tolist() == [0.0, 1800.0]
+    assert numpy.isfinite(sp["f_T"]).all() and numpy.isfinite(sp["f_u"]).all() and numpy.isfinite(sp["Tv"]).all()
+    assert numpy.isfinite(ex["Tv"]).all() and numpy.isfinite(ex["wthl"]).all()      # extra column kept its rows
+    assert numpy.isnan(ex["f_T"]).all()                                              # and received no SP tendencies

@@ -4,15 +4,23 @@
 One *step* = one pass of the hot path over one batch of synthetic columns:
     K1 forward (convert + interpolate + LES forcings, fused K2 cloud-fraction index map)  ->  K3 backward
     (interpolate back + GCM tendencies), i.e. one *column-exchange* per column.
-Workload at N=1: BASELINE.json configs[1] -- 1024 synthetic SP columns, 91 GCM <-> 160 LES levels, fp64.
-Inputs are resident in HBM before the timed region; ROTATE distinct batches (default 8 x 44 MB of
-live arrays > 256 MB Infinity Cache) are cycled so the kernels stream from HBM, not from cache.
-N>1 (launched by torch.distributed.run): weak scaling, every rank owns its own 1024-column batches,
-no data-path collective (columns are independent); only the barrier and the max-over-ranks of the
-elapsed time use RCCL.
 
-Prints ONE JSON line on rank 0 (contract: see the task statement); extra keys `roofline` and
-`cpu_baseline` as specified there.
+Workloads (BASELINE.json `configs`; the metric names no config, so N=1 runs the largest single-GPU one):
+    N = 1   config 3: T159 full-SP, 35 718 columns, 91 GCM <-> 160 LES levels, fp64, all on one MI355X.
+            Extra key `small_batch`: config 2 (1024 columns), the launch-latency-bound case, same measurements.
+    N > 1   config 4: T511 full-SP, 348 528 columns, column-sharded over the N ranks (contiguous blocks of
+            ceil(n/N) rows, sharding.shard_range) -- STRONG scaling of the stated workload; no data-path
+            collective (columns are independent); RCCL only for the barrier and the max-over-ranks of the time.
+Inputs are resident in HBM before the timed region; ROTATE distinct batches are cycled (one config-3 batch is
+1.6 GB of live arrays, already 6x the 256 MB Infinity Cache; config 2 rotates 8 x 44 MB).
+
+Byte model (LES grid SHARED by all columns as bench.py packs it -> zf/zh are not per-column
+traffic): K1+K2 (9 nG + 5 nL + 3) reads + (6 nL + 1) writes fp64 + nG int32; K3 (9 nG + 6 nL) reads + 7 nG writes.
+91<->160: 21 028 B + 19 328 B = 40 356 B per column-exchange.
+
+Prints ONE JSON line on rank 0 (contract: see the task statement) with the extra objects `roofline`,
+`cpu_baseline`, `small_batch`, and `verified` (outputs of batch 0 after the timed region, bit-compared with the
+CPU oracle's outputs that the cpu_baseline leg produced).
 """
 import argparse
 import ctypes
@@ -25,33 +33,42 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s measured copy)
+KERNEL_LAUNCHES = 400   # back-to-back launches per per-kernel HIP-event measurement (independent of --steps)
 
 
-def algorithmic_bytes(nG, nL, esize=8):
-    """SURVEY.md section 8(d) / BASELINE.md section 3, per column-exchange."""
-    fwd = (9 * nG + 6 * nL + 3) * esize + (6 * nL + 1) * esize
-    idx = nL * esize + nG * 4
-    bwd = (9 * nG + 7 * nL) * esize + 7 * nG * esize
+def algorithmic_bytes(nG, nL, esize=8, shared_grid=True):
+    """SURVEY.md section 8(d), per column-exchange; with a shared LES grid the 2 nL (fwd: zf, zh) and nL (bwd: zf)
+    grid reads are per-launch constants, not per-column traffic, and are subtracted as 8(d) says."""
+    fwd_r = (9 * nG + 6 * nL + 3) - (nL if shared_grid else 0)
+    idx_r = 0 if shared_grid else nL
+    bwd_r = (9 * nG + 7 * nL) - (nL if shared_grid else 0)
+    fwd = fwd_r * esize + (6 * nL + 1) * esize
+    idx = idx_r * esize + nG * 4
+    bwd = bwd_r * esize + 7 * nG * esize
     return {"forward": fwd, "index": idx, "backward": bwd, "k1_launch": fwd + idx, "k3_launch": bwd,
             "exchange": fwd + idx + bwd}
 
 
+# ---------------------------------------------------------------------------------------------
+# cpu_baseline: the reference's algorithm on the host (oracle/spcpl_oracle.py: serial Python loop over columns,
+# one numpy.interp per profile).  Its outputs double as the checker of `verified`.
+# ---------------------------------------------------------------------------------------------
 def cpu_baseline(gcm, zf, zh, prof, dt, factor, budget_s):
-    """The reference's algorithm on the host: serial Python loop over columns, one numpy.interp per
-    profile (oracle/spcpl_oracle.py).  Bounded sample: whole passes over the batch until budget_s."""
     from oracle import spcpl_oracle as orc
     n = gcm["T"].shape[0]
+    lean = {k: v for k, v in prof.items() if k not in ("Rain", "rain_last")}
     done, t0 = 0, time.perf_counter()
     while True:
-        f = orc.forward_batched(gcm, prof, zf, zh, factor, dt, couple_surface=False)
-        orc.backward_batched(gcm, f["Zf"], prof, zf, factor, dt)
+        f = orc.forward_batched(gcm, lean, zf, zh, factor, dt, couple_surface=False)
+        b = orc.backward_batched(gcm, f["Zf"], prof, zf, factor, dt)
         done += n
         el = time.perf_counter() - t0
         if el >= budget_s:
             break
-    return {"value": done / el, "unit": "column-exchanges/s", "cores": 1, "kind": "port",
-            "sample": "%d column-exchanges (%d passes over the %d-column batch, NumPy per-column loop, "
-                      "%.1f s)" % (done, done // n, n, el)}
+    res = {"value": done / el, "unit": "column-exchanges/s", "cores": 1, "kind": "port",
+           "sample": "%d column-exchanges (%d passes over the first %d columns of batch 0, NumPy per-column "
+                     "loop, %.1f s)" % (done, done // n, n, el)}
+    return res, f, b
 
 
 def cpu_worker_main(path, budget):
@@ -73,8 +90,8 @@ def cpu_worker_main(path, budget):
 
 
 def cpu_baseline_multicore(gcm, zf, zh, prof, budget_s, workers):
-    """the same per-column NumPy loop in `workers` independent CHILD PROCESSES
-    (plain subprocesses with a hard timeout -- no pool that could respawn; they never touch the GPU)."""
+    """The same per-column NumPy loop in `workers` independent CHILD PROCESSES (plain subprocesses with a hard
+    timeout -- no pool that could respawn; they never touch the GPU)."""
     import subprocess
     import tempfile
     import numpy
@@ -113,25 +130,97 @@ def cpu_baseline_multicore(gcm, zf, zh, prof, budget_s, workers):
             "sample": "%d column-exchanges in %d processes x %.1f s (NumPy per-column loop)" % (total, len(res), wall)}
 
 
+def verify(fplan, bplan, ref_f, ref_b, n_ref, factor, dt):
+    """Outputs of batch 0 (left in HBM by the timed launches) against the oracle outputs of the cpu_baseline
+    leg: index map and everything not downstream of pow() bit-exact; f_thl within 8 ulp of thl's scale / dt."""
+    import numpy
+    eps = 2.220446049250313e-16
+    bad = []
+
+    def bits(name, got, want):
+        got, want = got[:n_ref], want[:n_ref]
+        same = (got == want) | (numpy.isnan(got) & numpy.isnan(want))
+        if not same.all() or not numpy.array_equal(numpy.signbit(got)[~numpy.isnan(want)], numpy.signbit(want)[~numpy.isnan(want)]):
+            bad.append("%s: %d elements differ" % (name, int((~same).sum())))
+    F = {k: v.cpu().numpy() for k, v in fplan.outputs.items()}
+    B = {k: v.cpu().numpy() for k, v in bplan.outputs.items()}
+    bits("idx", F["idx"], ref_f["idx"].astype(F["idx"].dtype))
+    for k in ("f_u", "f_v", "f_qt", "f_ql", "ql_ref", "f_ps"):
+        bits(k, F[k], ref_f[k])
+    for k in ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A"):
+        bits(k, B[k], ref_b[k])
+    err = float(numpy.abs(F["f_thl"][:n_ref] - ref_f["f_thl"]).max())
+    bound = 8 * eps * float(numpy.abs(ref_f["thl"]).max()) * abs(factor) / dt
+    if not err <= bound:
+        bad.append("f_thl: max abs err %.3e > %.3e" % (err, bound))
+    rel = err / float(numpy.abs(ref_f["f_thl"]).max())
+    return (not bad), {"columns_checked": int(n_ref), "bit_exact": "idx,f_u,f_v,f_qt,f_ql,ql_ref,f_ps,f_T,f_SH,f_QL,f_QI,f_U,f_V,f_A",
+                       "f_thl_max_rel_err": rel, "failures": bad}
+
+
+class Workload:
+    """ROTATE batches of one configuration resident in HBM + the exchange plans bench.py times."""
+
+    def __init__(self, eng, n_cols, nG, nL, seed, rotate, factor, dt, cols_per_block=0, keep_host=False):
+        import torch
+        from sp_coupler_amd import synthetic
+        self.n_cols, self.nG, self.nL, self.rotate = n_cols, nG, nL, rotate
+        self.fplans, self.bplans, self.host0 = [], [], None
+        for r in range(rotate):
+            gcm, zf, zh, prof = synthetic.make_batch_tiled(n_cols, nG, nL, seed=seed + r, couple_surface=False)
+            if r == 0 and keep_host:
+                self.host0 = (gcm, zf, zh, prof)
+            g = {k: torch.from_numpy(v).to(eng.device) for k, v in gcm.items()}
+            p = {k: torch.from_numpy(v).to(eng.device) for k, v in prof.items()}
+            zf_d, zh_d = torch.from_numpy(zf).to(eng.device), torch.from_numpy(zh).to(eng.device)
+            fp, bp = eng.plan_exchange(g, zf_d, zh_d, p, factor, factor, dt, cols_per_block=cols_per_block)
+            self.fplans.append(fp)
+            self.bplans.append(bp)
+
+    def step(self, i, sptr):
+        self.fplans[i % self.rotate].launch_raw(sptr)
+        self.bplans[i % self.rotate].launch_raw(sptr)
+
+    def kernel_times(self, stream, sptr, launches=KERNEL_LAUNCHES):
+        """Average duration of K1 alone and K3 alone: HIP events (recorded on the launch stream) around `launches`
+        back-to-back launches of the one kernel over the rotating batches (inter-kernel gap ~40 ns in rocprofv3
+        traces); the figure rocprofv3 --kernel-trace --stats reproduces (profiles/)."""
+        import torch
+        res = {}
+        for name, plans in (("k1", self.fplans), ("k3", self.bplans)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for i in range(16):
+                plans[i % self.rotate].launch_raw(sptr)
+            torch.cuda.synchronize()
+            e0.record(stream)
+            for i in range(launches):
+                plans[i % self.rotate].launch_raw(sptr)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            res[name] = e0.elapsed_time(e1) * 1e3 / launches
+        return res["k1"], res["k3"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--config", type=int, default=2, help="BASELINE.md config id (2 = 1024 cols, 91<->160)")
-    ap.add_argument("--cols", type=int, default=None, help="override columns per GPU")
-    ap.add_argument("--rotate", type=int, default=8, help="distinct batches cycled through (cache defeat)")
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--config", type=int, default=None, help="BASELINE.md config id (default: 3 at N=1, 4 sharded at N>1)")
+    ap.add_argument("--cols", type=int, default=None, help="override the TOTAL column count of the workload")
+    ap.add_argument("--rotate", type=int, default=None, help="distinct batches cycled through (default 2; 8 for <= 4096 cols)")
     ap.add_argument("--cols-per-block", type=int, default=0)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip; also skips `verified`)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--no-cpu-multicore", action="store_true", help="skip the all-cores cpu_baseline extra")
+    ap.add_argument("--no-small-batch", action="store_true", help="skip the config-2 extra at N=1")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N>1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--device", type=int, default=None, help="force this HIP device for every rank (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
 
     import numpy
     import torch
-    from sp_coupler_amd import synthetic
+    from sp_coupler_amd import sharding, synthetic
     from sp_coupler_amd.engine import Engine
 
     rank = int(os.environ.get("RANK", "0"))
@@ -146,49 +235,28 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        if args.backend == "nccl":
-            try:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-                probe = torch.zeros(1, device="cuda:%d" % local)
-                dist.all_reduce(probe)                      # fail here, not in the timed region
-                torch.cuda.synchronize()
-            except Exception as e:                          # the data path needs no collective: gloo is enough
-                print("bench.py: RCCL unavailable (%r), using gloo for barrier/max" % (e,), file=sys.stderr)
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                args.backend = "gloo"
-                dist.init_process_group("gloo")
+        if args.backend == "nccl":      # RCCL; a failure here is an error, not a silent change of backend
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            probe = torch.zeros(1, device="cuda:%d" % local)
+            dist.all_reduce(probe)      # fail here, not in the timed region
+            torch.cuda.synchronize()
         else:
             dist.init_process_group(args.backend)
 
-    n_cols, nG, nL, seed = synthetic.CONFIGS[args.config]
+    cfg = args.config if args.config is not None else (3 if world == 1 else 4)
+    total_cols, nG, nL, seed = synthetic.CONFIGS[cfg]
     if args.cols:
-        n_cols = args.cols
+        total_cols = args.cols
+    lo, hi = sharding.shard_range(total_cols, rank, world)       # contiguous row block of this rank
+    n_cols = hi - lo
+    rotate = args.rotate or (8 if n_cols <= 4096 else 2)
     dt_gcm, factor = 900.0, 1.0
     eng = Engine("cuda:%d" % local)
-    stream = torch.cuda.current_stream()
+    stream = torch.cuda.current_stream(eng.device)
     sptr = ctypes.c_void_p(stream.cuda_stream)
 
-    fplans, bplans, host0 = [], [], None
-    for r in range(args.rotate):
-        gcm, zf, zh, prof = synthetic.make_batch(n_cols, nG, nL, seed=seed + 1000 * rank + r, couple_surface=False)
-        # hot path only: the rain-rate diagnostic (spcpl.py:325, written to spifs only) is not part of the byte model
-        prof = {k: v for k, v in prof.items() if k not in ("Rain", "rain_last")}
-        if r == 0:
-            host0 = (gcm, zf, zh, prof)
-        g = {k: torch.from_numpy(v).to(eng.device) for k, v in gcm.items()}
-        p = {k: torch.from_numpy(v).to(eng.device) for k, v in prof.items()}
-        zf_d, zh_d = torch.from_numpy(zf).to(eng.device), torch.from_numpy(zh).to(eng.device)
-        # K1 writes only the arrays the algorithmic-byte model counts (+ idx); K3 recomputes Zf from geopotential
-        fplans.append(eng.plan_forward(g, zf_d, p, factor, dt_gcm, zh=zh_d, want_heights=False,
-                                       cols_per_block=args.cols_per_block))
-        bplans.append(eng.plan_backward(g, zf_d, p, factor, dt_gcm, Zf=None, want_start_index=False,
-                                        cols_per_block=args.cols_per_block))
-    R = args.rotate
-
-    def step(i):
-        fplans[i % R].launch_raw(sptr)
-        bplans[i % R].launch_raw(sptr)
+    wl = Workload(eng, n_cols, nG, nL, seed + 1000 * rank, rotate, factor, dt_gcm, args.cols_per_block,
+                  keep_host=(rank == 0 and world == 1))
 
     def fence():
         torch.cuda.synchronize()
@@ -197,11 +265,11 @@ def main():
             torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        step(i)
+        wl.step(i, sptr)
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        wl.step(i, sptr)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     fence()
@@ -210,65 +278,16 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # ---- per-kernel durations with HIP events on the launch stream (same plans, same rotating batches).
-    # (a) event pairs bracketing every kernel of `ke` further steps; an event pair costs a few us of its
-    #     own on this stack, measured live with empty pairs and subtracted;
-    # (b) K1 alone / K3 alone, `ke` back-to-back launches between two events (inter-kernel gap ~40 ns
-    #     in the rocprofv3 trace), the figure the roofline uses.
     ab = algorithmic_bytes(nG, nL)
     k1_us = k3_us = None
     kdiag = {}
-    if not args.no_kernel_events:
-        ke = min(args.steps, 400)
-        E = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
-        evs = [[E() for _ in range(3)] for _ in range(ke)]
-        emp = [[E() for _ in range(2)] for _ in range(64)]
-        torch.cuda.synchronize()
-        for i in range(ke):
-            evs[i][0].record(stream)
-            fplans[i % R].launch_raw(sptr)
-            evs[i][1].record(stream)
-            bplans[i % R].launch_raw(sptr)
-            evs[i][2].record(stream)
-        for a, b in emp:
-            a.record(stream)
-            b.record(stream)
-        torch.cuda.synchronize()
-        empty = float(numpy.median([a.elapsed_time(b) for a, b in emp])) * 1e3
-        kdiag["event_pair_k1_us"] = float(numpy.mean([e[0].elapsed_time(e[1]) for e in evs])) * 1e3
-        kdiag["event_pair_k3_us"] = float(numpy.mean([e[1].elapsed_time(e[2]) for e in evs])) * 1e3
-        kdiag["empty_event_pair_us"] = empty
-        res = {}
-        for name, plans in (("k1", fplans), ("k3", bplans)):
-            e0, e1 = E(), E()
-            for i in range(32):
-                plans[i % R].launch_raw(sptr)
-            torch.cuda.synchronize()
-            e0.record(stream)
-            for i in range(ke):
-                plans[i % R].launch_raw(sptr)
-            e1.record(stream)
-            torch.cuda.synchronize()
-            res[name] = e0.elapsed_time(e1) * 1e3 / ke
-        k1_us, k3_us = res["k1"], res["k3"]
-        # the same kernels re-launched on ONE batch (inputs resident in the 256 MB Infinity Cache): reported as the
-        # warm half of the cold/warm pair BASELINE.md section 3 asks for; never used for `value` or `roofline.frac`
-        for name, plans in (("k1_warm", fplans), ("k3_warm", bplans)):
-            e0, e1 = E(), E()
-            for i in range(32):
-                plans[0].launch_raw(sptr)
-            torch.cuda.synchronize()
-            e0.record(stream)
-            for i in range(ke):
-                plans[0].launch_raw(sptr)
-            e1.record(stream)
-            torch.cuda.synchronize()
-            kdiag[name + "_us"] = e0.elapsed_time(e1) * 1e3 / ke
-
-    # measured device-to-device copy rate of this box (16 B/lane streaming copy, 256 MiB, read + write bytes):
-    # the practical HBM ceiling reported next to the 8 TB/s spec peak
     copy_gbs = None
     if not args.no_kernel_events:
+        k1_us, k3_us = wl.kernel_times(stream, sptr)
+        # warm half of the cold/warm pair: the same kernel re-launched on ONE batch; at
+        # config 3 one batch is 6x the Infinity Cache so this equals the cold figure, at config 2 it does not
+        # measured device-to-device copy rate of this box (16 B/lane streaming copy, 256 MiB, read + write bytes):
+        # the practical HBM ceiling reported next to the 8 TB/s spec peak
         src = torch.empty(1 << 28, dtype=torch.uint8, device=eng.device)
         dst = torch.empty_like(src)
         for _ in range(3):
@@ -282,52 +301,96 @@ def main():
         copy_gbs = 2.0 * src.numel() * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
         del src, dst
 
+    small = None
+    if world == 1 and not args.no_small_batch and not args.no_kernel_events and cfg != 2:
+        n2, nG2, nL2, seed2 = synthetic.CONFIGS[2]
+        w2 = Workload(eng, n2, nG2, nL2, seed2, 8, factor, dt_gcm, args.cols_per_block)
+        for i in range(200):
+            w2.step(i, sptr)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for i in range(2000):
+            w2.step(i, sptr)
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t2
+        a2 = algorithmic_bytes(nG2, nL2)
+        s1, s3 = w2.kernel_times(stream, sptr)
+        small = {"workload": "config 2: 1024 synthetic SP columns, 91 GCM <-> 160 LES levels, fp64, 8 rotating "
+                             "batches (cold: 8 x 41 MB > Infinity Cache)", "value": n2 * 2000 / el2,
+                 "unit": "column-exchanges/s", "steps": 2000, "ms_per_step": el2 / 2000 * 1e3,
+                 "k1_avg_launch_us": s1, "k3_avg_launch_us": s3,
+                 "k1_frac": a2["k1_launch"] * n2 / (s1 * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                 "k3_frac": a2["k3_launch"] * n2 / (s3 * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                 "k1_algorithmic_bytes_per_launch": a2["k1_launch"] * n2,
+                 "k3_algorithmic_bytes_per_launch": a2["k3_launch"] * n2}
+        del w2
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    total_cols = n_cols * world * args.steps
-    value = total_cols / elapsed
+    value = total_cols * args.steps / elapsed
+    if world == 1:
+        wtxt = ("config %d: %d synthetic SP columns on one GPU, %d GCM <-> %d LES levels, fp64, shared LES grid, "
+                "%d rotating batches resident in HBM" % (cfg, total_cols, nG, nL, rotate))
+    else:
+        wtxt = ("config %d: %d synthetic SP columns column-sharded over %d GPUs (%d per GPU, contiguous row blocks), "
+                "%d GCM <-> %d LES levels, fp64, shared LES grid, %d rotating batches per GPU"
+                % (cfg, total_cols, world, n_cols, nG, nL, rotate))
     out = {
         "metric": "SP column-exchanges/sec (GCM<->LES forcing+tendency)",
         "value": value, "unit": "column-exchanges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "config %d: %d synthetic SP columns per GPU, %d GCM <-> %d LES levels, fp64, "
-                               "%d rotating batches resident in HBM" % (args.config, n_cols, nG, nL, R),
-                   "n_cols_per_gpu": n_cols, "nG": nG, "nL": nL, "rotate": R,
-                   "launches_per_step": 2, "parallelism": "columns sharded, no collective"},
+        "config": {"workload": wtxt, "total_cols": total_cols, "n_cols_per_gpu": n_cols, "nG": nG, "nL": nL,
+                   "rotate": rotate, "launches_per_step": 2, "parallelism": "columns sharded, no collective"},
+        "backend": (args.backend if world > 1 else None),
         "bytes_per_exchange": ab["exchange"],
         "hbm_frac_whole_step": value / world * ab["exchange"] / 1e9 / HBM_PEAK_GBS,
     }
     if k1_us is not None:
-        traffic = None
+        traffic, tsrc = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))     # PMC passes of tools/gpu_round.sh (separate --pmc runs, calibrated)
                 if tj.get("n_cols") == n_cols and (nG, nL) == (91, 160):
                     traffic = tj.get("k_forward_bytes_per_launch")
+                    tsrc = "profiles/traffic.json (builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on another box, %s)" % tj.get("tag", "this round")
             except Exception:
                 traffic = None
         ach = ab["k1_launch"] * n_cols / (k1_us * 1e-6) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "k_forward<double,false> (K1+K2 fused)", "achieved": ach,
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+        out["roofline"] = {"bound": "hbm", "kernel": "k_forward (K1, fused K2 index map), lean hot-path variant",
+                           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                           "traffic": traffic, "traffic_source": tsrc,
+                           "frac_vs_pmc": (traffic / (k1_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                            "algorithmic_bytes_per_launch": ab["k1_launch"] * n_cols, "avg_launch_us": k1_us,
+                           "launches_timed": KERNEL_LAUNCHES,
                            "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": (ach / copy_gbs) if copy_gbs else None,
-                           "timing": dict(kdiag, method="HIP events around %d back-to-back launches of the kernel "
-                                          "alone on the launch stream" % min(args.steps, 400)),
-                           "backward": {"kernel": "k_backward<double> (K3)", "avg_launch_us": k3_us,
+                           "timing": dict(kdiag, method="HIP events on the launch stream around %d back-to-back launches "
+                                          "of the kernel alone over the rotating batches" % KERNEL_LAUNCHES),
+                           "backward": {"kernel": "k_backward (K3)", "avg_launch_us": k3_us,
                                         "achieved": ab["k3_launch"] * n_cols / (k3_us * 1e-6) / 1e9,
+                                        "frac": ab["k3_launch"] * n_cols / (k3_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                         "algorithmic_bytes_per_launch": ab["k3_launch"] * n_cols}}
+    if small is not None:
+        out["small_batch"] = small
+    out["verified"] = None
     if args.cpu_seconds > 0 and world == 1:
-        gcm, zf, zh, prof = host0
-        out["cpu_baseline"] = cpu_baseline(gcm, zf, zh, prof, dt_gcm, factor, args.cpu_seconds)
+        gcm, zf, zh, prof = wl.host0
+        m = min(n_cols, 8192)             # bounded sample: the first m columns of batch 0, whole passes
+        gs = {k: numpy.ascontiguousarray(v[:m]) for k, v in gcm.items()}
+        ps = {k: numpy.ascontiguousarray(v[:m]) for k, v in prof.items()}
+        base, ref_f, ref_b = cpu_baseline(gs, zf, zh, ps, dt_gcm, factor, args.cpu_seconds)
+        out["cpu_baseline"] = base
+        # batch 0 was last written by the per-kernel loops above with the same inputs: check it
+        ok, detail = verify(wl.fplans[0], wl.bplans[0], ref_f, ref_b, m, factor, dt_gcm)
+        out["verified"], out["verified_detail"] = ok, detail
         workers = min(16, os.cpu_count() or 1)
         if workers > 1 and not args.no_cpu_multicore:
             try:
-                out["cpu_baseline"]["all_cores"] = cpu_baseline_multicore(gcm, zf, zh, prof, min(6.0, args.cpu_seconds), workers)
+                out["cpu_baseline"]["all_cores"] = cpu_baseline_multicore(gs, zf, zh, ps, min(6.0, args.cpu_seconds), workers)
             except Exception as e:                       # a reported extra, never fatal
                 out["cpu_baseline"]["all_cores"] = {"error": repr(e)}
     elif args.cpu_seconds > 0:
@@ -335,6 +398,8 @@ def main():
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    if out["verified"] is False:
+        sys.exit("bench.py: outputs of the timed plans differ from the oracle: %s" % out["verified_detail"]["failures"])
 
 
 if __name__ == "__main__":

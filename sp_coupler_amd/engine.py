@@ -292,6 +292,18 @@ class Engine:
     def backward(self, *args, stream=None, **kw):
         return self.plan_backward(*args, **kw).launch(stream)
 
+    # -- the hot-path pair: what a steady-state step launches, and what bench.py / tools time -------
+    def plan_exchange(self, gcm, zf, zh, prof, factor_les, factor_gcm, dt, cols_per_block=0):
+        """(ForwardPlan, BackwardPlan) of one column-exchange with ONLY the outputs SURVEY 8(d) counts: K1 writes
+        the six setter arrays + f_ps + the fused index map (no optional profiles / heights / rain rate), K3
+        recomputes Zf from the geopotential (no Zf round trip) and writes the seven tendencies."""
+        lean = {k: v for k, v in prof.items() if k not in ("Rain", "rain_last")}
+        fp = self.plan_forward(gcm, zf, lean, factor_les, dt, zh=zh, want_profiles=False, want_heights=False,
+                               cols_per_block=cols_per_block)
+        bp = self.plan_backward(gcm, zf, prof, factor_gcm, dt, Zf=None, want_start_index=False,
+                                cols_per_block=cols_per_block)
+        return fp, bp
+
     # -- K5 ---------------------------------------------------------------------------------
     def diagnostics(self, gcm, zf=None, prof=None, stream=None, cols_per_block=0):
         """spifs.nc diagnostics: Tv, THL, QT, Zf, Zh (splib/spcpl.py:176,197-198,214-215) and, when

@@ -146,6 +146,28 @@ def make_batch(n_cols, nG=91, nL=160, seed=20261006, couple_surface=True, per_co
     return gcm, zf, zh, prof
 
 
+def make_batch_tiled(n_cols, nG=91, nL=160, seed=20261006, base=8192, couple_surface=True):
+    """``n_cols`` columns built from a ``base``-column synthetic batch, tiled with a per-tile perturbation of the
+    state (heights untouched, so they stay monotone): the generator itself needs minutes for the 3.5e5 columns of
+    config 4.  Used for the full-size benchmark / test batches; every column still differs from every other."""
+    if n_cols <= base:
+        return make_batch(n_cols, nG, nL, seed, couple_surface)
+    gcm, zf, zh, prof = make_batch(base, nG, nL, seed, couple_surface)
+    reps = -(-n_cols // base)
+    tile = numpy.repeat(numpy.arange(reps, dtype=numpy.float64), base)[:n_cols]
+
+    def rep(a):
+        return numpy.ascontiguousarray(numpy.concatenate([a] * reps, axis=0)[:n_cols])
+    g = {k: rep(v) for k, v in gcm.items()}
+    p = {k: rep(v) for k, v in prof.items()}
+    g["T"] += 0.01 * tile[:, None]
+    g["U"] *= (1.0 + 1e-3 * tile[:, None])
+    p["THL"] += 0.02 * tile[:, None]
+    p["V"] -= 0.05 * tile[:, None]
+    p["PS"] += tile
+    return g, zf, zh, p
+
+
 def make_config(cfg_id, n_cols=None):
     n, nG, nL, seed = CONFIGS[cfg_id]
     return make_batch(n if n_cols is None else n_cols, nG, nL, seed)

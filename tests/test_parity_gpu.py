@@ -320,3 +320,46 @@ def test_random_geometries_pitches_and_slab_sizes(eng):
                 check_backward({k: host(v) for k, v in bc.items()}, ref_c)
         except AssertionError as e:
             raise AssertionError(tag + ": " + str(e))
+
+
+def _pad_pitch(t, pad):
+    if pad == 0 or t.dim() != 2:
+        return t
+    buf = torch.full((t.shape[0], t.shape[1] + pad), float("nan"), device=t.device, dtype=t.dtype)
+    buf[:, :t.shape[1]] = t
+    return buf[:, :t.shape[1]]
+
+
+@pytest.mark.parametrize("cfg,pad", [(2, 0), (3, 0), (2, 3), (3, 5)])
+def test_the_plans_bench_py_times_are_bit_checked(eng, cfg, pad):
+    """Round-1 verdict: the kernels the benchmark times had no parity test.  This builds EXACTLY what bench.py,
+    tools/kbench.py and tools/pmc_run.py launch -- Engine.plan_exchange (lean K1: no optional outputs, no rain
+    rate, fused index map; K3 with Zf recomputed and no start_index) through launch_raw -- on config 2 (small
+    launch: write-through stores) and config 3 (large launch: plain stores), with contiguous columns (compile-time
+    geometry kernels) and with a padded pitch (run-time-geometry kernels), and bit-compares every output with the
+    plain-C oracle: f_u, f_v, f_qt, f_ql, ql_ref, f_ps, idx and the seven tendencies (f_thl <= 8 ulp of thl / dt)."""
+    import ctypes
+    gcm, zf, zh, prof = synthetic.make_config(cfg)
+    g = {k: _pad_pitch(v, pad) for k, v in to_dev(gcm, eng.device).items()}
+    p = {k: _pad_pitch(v, pad) for k, v in to_dev(prof, eng.device).items()}
+    zf_d, zh_d = torch.from_numpy(zf).to(eng.device), torch.from_numpy(zh).to(eng.device)
+    fp, bp = eng.plan_exchange(g, zf_d, zh_d, p, FACTOR, FACTOR, DT)
+    assert set(fp.outputs) == {"f_u", "f_v", "f_thl", "f_qt", "f_ql", "ql_ref", "f_ps", "idx"}
+    assert set(bp.outputs) == {"f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A"}
+    for t in list(fp.outputs.values()) + list(bp.outputs.values()):
+        t.fill_(float("nan")) if t.is_floating_point() else t.fill_(-7)
+    sptr = ctypes.c_void_p(torch.cuda.current_stream(eng.device).cuda_stream)
+    fp.launch_raw(sptr)
+    bp.launch_raw(sptr)
+    torch.cuda.synchronize()
+    ref_f = oracle_c.forward(gcm, zf, zh, prof, FACTOR, DT, couple_surface=False)
+    ref_b = oracle_c.backward(gcm, None, zf, prof, FACTOR, DT)
+    F = {k: host(v) for k, v in fp.outputs.items()}
+    assert_bits("idx", F["idx"], ref_f["idx"])
+    for k in ("f_u", "f_v", "f_qt", "f_ql", "ql_ref", "f_ps"):
+        assert_bits(k, F[k], ref_f[k])
+    thl_scale = numpy.abs(ref_f["thl"]).max()
+    assert_close_scaled("f_thl", F["f_thl"], ref_f["f_thl"], 8 * EPS, thl_scale * abs(FACTOR) / DT)
+    assert_close_scaled("f_thl(1e-10)", F["f_thl"], ref_f["f_thl"], REL_TOL, numpy.abs(ref_f["f_thl"]).max())
+    for k in ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A"):
+        assert_bits(k, host(bp.outputs[k]), ref_b[k])

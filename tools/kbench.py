@@ -15,9 +15,10 @@ from sp_coupler_amd.engine import Engine  # noqa: E402
 
 
 def bytes_model(nG, nL):
-    fwd = (9 * nG + 6 * nL + 3) * 8 + (6 * nL + 1) * 8 + nL * 8 + nG * 4
-    bwd = (9 * nG + 7 * nL) * 8 + 7 * nG * 8
-    return fwd, bwd
+    """bench.py's model: SURVEY 8(d) with the shared LES grid subtracted (honest per-column traffic)"""
+    from bench import algorithmic_bytes
+    ab = algorithmic_bytes(nG, nL)
+    return ab["k1_launch"], ab["k3_launch"]
 
 
 def main():
@@ -42,14 +43,13 @@ def main():
         rot = max(2, min(16, int(600e6 // live) + 1))
         data = []
         for r in range(rot):
-            gcm, zf, zh, prof = synthetic.make_batch(n, nG, nL, seed=100 + r, couple_surface=False)
-            prof = {k: v for k, v in prof.items() if k not in ("Rain", "rain_last")}      # lean hot path, as bench.py
+            gcm, zf, zh, prof = synthetic.make_batch_tiled(n, nG, nL, seed=100 + r, couple_surface=False)
             g = {k: torch.from_numpy(v).to(eng.device, dtype) for k, v in gcm.items()}
             p = {k: torch.from_numpy(v).to(eng.device, dtype) for k, v in prof.items()}
             data.append((g, torch.from_numpy(zf).to(eng.device, dtype), torch.from_numpy(zh).to(eng.device, dtype), p))
         for cb in (int(x) for x in a.cbs.split(",")):
-            fpl = [eng.plan_forward(g, zf, p, 1.0, 900.0, zh=zh, want_heights=False, cols_per_block=cb) for g, zf, zh, p in data]
-            bpl = [eng.plan_backward(g, zf, p, 1.0, 900.0, want_start_index=False, cols_per_block=cb) for g, zf, zh, p in data]
+            pl = [eng.plan_exchange(g, zf, zh, p, 1.0, 1.0, 900.0, cols_per_block=cb) for g, zf, zh, p in data]   # as bench.py
+            fpl, bpl = [x[0] for x in pl], [x[1] for x in pl]
             res = {}
             for name, plans in (("K1", fpl), ("K3", bpl)):
                 for i in range(20):

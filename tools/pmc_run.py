@@ -19,13 +19,13 @@ eng = Engine("cuda:0")
 sptr = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 fpl, bpl = [], []
 for r in range(rot):
-    gcm, zf, zh, prof = synthetic.make_batch(n, 91, 160, seed=500 + r, couple_surface=False)
-    prof = {k: v for k, v in prof.items() if k not in ("Rain", "rain_last")}
+    gcm, zf, zh, prof = synthetic.make_batch_tiled(n, 91, 160, seed=500 + r, couple_surface=False)
     g = {k: torch.from_numpy(v).cuda() for k, v in gcm.items()}
     p = {k: torch.from_numpy(v).cuda() for k, v in prof.items()}
     zf_d, zh_d = torch.from_numpy(zf).cuda(), torch.from_numpy(zh).cuda()
-    fpl.append(eng.plan_forward(g, zf_d, p, 1.0, 900.0, zh=zh_d, want_heights=False))
-    bpl.append(eng.plan_backward(g, zf_d, p, 1.0, 900.0, want_start_index=False))
+    fp, bp = eng.plan_exchange(g, zf_d, zh_d, p, 1.0, 1.0, 900.0)      # exactly what bench.py times
+    fpl.append(fp)
+    bpl.append(bp)
 src = torch.empty(1 << 28, dtype=torch.uint8, device="cuda").random_(0, 255)      # 256 MiB
 dst = torch.empty_like(src)
 torch.cuda.synchronize()

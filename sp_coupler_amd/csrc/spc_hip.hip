@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <initializer_list>
 #include <type_traits>
 #include <unordered_map>
 
@@ -662,6 +663,8 @@ template <typename T, int NG, int NL, int WT> __global__ __launch_bounds__(BLOCK
     }
 }
 
+#include "spc_v2.hpp"
+
 // =================================================================================================
 // K4 backward, conservative coarsening: splib/spcpl.py:479-489 -> sputils.interp_c / integral
 // (splib/sputils.py:94-189).  Same tendencies / masking as K3, but each GCM level receives the
@@ -1041,6 +1044,94 @@ int launch_status(const char *what)
 #define REQUIRE(ptr, name) \
     if (!(ptr)) return fail(SPC_ERR_INVALID_ARGUMENT, "required pointer %s is NULL", name)
 
+// ---- second-generation kernels (spc_v2.hpp): fp64, compile-time geometry, lean outputs -------------------
+// SPC_V2=0 disables them (A/B against the first-generation kernels); SPC_V2_K1 / SPC_V2_K3 = "cb,block" pick a
+// specific instantiated variant; SPC_V2_REMAP=0/1 overrides the XCD-contiguous slab mapping.
+int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+bool env_pair(const char *name, int *a, int *b)
+{
+    const char *e = getenv(name);
+    return e && sscanf(e, "%d,%d", a, b) == 2;
+}
+
+bool aligned16(std::initializer_list<const void *> ptrs)
+{
+    for (const void *q : ptrs)
+        if (((uintptr_t)q & 15u) != 0) return false;
+    return true;
+}
+
+struct V2Choice { int cb, block; };
+
+// measured choice per batch size (profiles/r02_*): small launches want many small workgroups, large ones longer slabs
+V2Choice v2_pick(const char *env, int64_t n_cols, int nL)
+{
+    V2Choice c;
+    if (env_pair(env, &c.cb, &c.block)) return c;
+    if (nL == 512) return V2Choice{2, 512};
+    if (n_cols <= 2048) return V2Choice{2, 192};
+    return V2Choice{4, 256};
+}
+
+template <int NG, int NL, int CB, int BLOCK_>
+int launch_fwd_v2(const spc_dims *d, FwdP<double, false> &p, int wt, hipStream_t stream)
+{
+    const bool with_idx = p.idx != nullptr;
+    const size_t smem = ((size_t)CB * NG * 7 + (with_idx ? (d->les_grid_shared ? (size_t)NL : (size_t)CB * NL) : 0)) * sizeof(double);
+    p.d = make_dims(d, CB);
+    p.d.xcd_remap = env_int("SPC_V2_REMAP", 1);
+    const unsigned grid = (unsigned)((d->n_cols + CB - 1) / CB);
+    auto k0 = k_forward_v2<NG, NL, CB, BLOCK_, 0>;
+    auto k1 = k_forward_v2<NG, NL, CB, BLOCK_, 1>;
+    int rc = ensure_lds(wt ? k1 : k0, smem, "forward");
+    if (rc) return rc;
+    hipLaunchKernelGGL(wt ? k1 : k0, dim3(grid), dim3(BLOCK_), smem, stream, p);
+    return launch_status("k_forward_v2");
+}
+
+template <int NG, int NL, int CB, int BLOCK_>
+int launch_bwd_v2(const spc_dims *d, BwdP<double> &p, int wt, hipStream_t stream)
+{
+    const size_t smem = ((size_t)CB * NL * 6 + (size_t)CB * NG + (d->les_grid_shared ? (size_t)NL : (size_t)CB * NL)) * sizeof(double);
+    p.d = make_dims(d, CB);
+    p.d.xcd_remap = env_int("SPC_V2_REMAP", 1);
+    const unsigned grid = (unsigned)((d->n_cols + CB - 1) / CB);
+    auto k0 = k_backward_v2<NG, NL, CB, BLOCK_, 0>;
+    auto k1 = k_backward_v2<NG, NL, CB, BLOCK_, 1>;
+    int rc = ensure_lds(wt ? k1 : k0, smem, "backward");
+    if (rc) return rc;
+    hipLaunchKernelGGL(wt ? k1 : k0, dim3(grid), dim3(BLOCK_), smem, stream, p);
+    return launch_status("k_backward_v2");
+}
+
+// instantiated (geometry, slab, workgroup) variants; -1 = not available -> first-generation kernel
+#define SPC_V2_VARIANTS(X) \
+    X(91, 160, 2, 128) X(91, 160, 2, 192) X(91, 160, 4, 256) X(91, 160, 4, 320) X(91, 160, 8, 512) \
+    X(137, 512, 2, 512) X(137, 512, 2, 256) X(19, 160, 4, 256) X(19, 160, 4, 320)
+
+int dispatch_fwd_v2(const spc_dims *d, FwdP<double, false> &p, int wt, hipStream_t stream, V2Choice c)
+{
+#define X(NG_, NL_, CB_, BL_) \
+    if (d->nG == NG_ && d->nL == NL_ && c.cb == CB_ && c.block == BL_) return launch_fwd_v2<NG_, NL_, CB_, BL_>(d, p, wt, stream);
+    SPC_V2_VARIANTS(X)
+#undef X
+    return 1;   // no such variant
+}
+
+int dispatch_bwd_v2(const spc_dims *d, BwdP<double> &p, int wt, hipStream_t stream, V2Choice c)
+{
+#define X(NG_, NL_, CB_, BL_) \
+    if (d->nG == NG_ && d->nL == NL_ && c.cb == CB_ && c.block == BL_) return launch_bwd_v2<NG_, NL_, CB_, BL_>(d, p, wt, stream);
+    SPC_V2_VARIANTS(X)
+#undef X
+    return 1;
+}
+
 template <typename T> int forward_impl(const spc_dims *d, const spc_forward_args *a, void *stream)
 {
     int rc = validate(d);
@@ -1100,6 +1191,15 @@ template <typename T> int forward_impl(const spc_dims *d, const spc_forward_args
     } else {
         FwdP<T, false> p;
         fill(p);
+        if constexpr (std::is_same<T, double>::value) {
+            if (geo != 0 && d->cols_per_block == 0 && env_int("SPC_V2", 1) &&
+                aligned16({a->U, a->V, a->T, a->SH, a->QL, a->QI, a->Pf, a->Zgfull, a->zf, a->zh, a->u_d, a->v_d, a->thl_d, a->qt_d,
+                           a->ql_d, a->f_u, a->f_v, a->f_thl, a->f_qt, a->f_ql, a->ql_ref})) {
+                rc = dispatch_fwd_v2(d, p, wt, (hipStream_t)stream, v2_pick("SPC_V2_K1", d->n_cols, d->nL));
+                if (rc <= 0) return rc;
+                fill(p);
+            }
+        }
         if ((rc = ensure_lds(klean[wt][geo], smem, "forward"))) return rc;
         hipLaunchKernelGGL(klean[wt][geo], dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
     }
@@ -1161,6 +1261,15 @@ template <typename T> int backward_impl(const spc_dims *d, const spc_backward_ar
     CP(t_d); CP(qt_d); CP(ql_d); CP(ql_ice_d); CP(u_d); CP(v_d); CP(A_prof); CP(zh); CP(Zh); CP(rhobf_d);
     p.factor = (T)a->factor; p.dt = (T)a->dt;
     OP(f_T); OP(f_SH); OP(f_QL); OP(f_QI); OP(f_U); OP(f_V); OP(f_A); p.start_index = a->start_index;
+    if constexpr (std::is_same<T, double>::value) {
+        if (!cons && geo != 0 && d->cols_per_block == 0 && env_int("SPC_V2", 1) &&
+            aligned16({a->T, a->SH, a->QL, a->QI, a->U, a->V, a->A, a->Zf, a->Zgfull, a->zf, a->t_d, a->qt_d, a->ql_d, a->ql_ice_d,
+                       a->u_d, a->v_d, a->f_T, a->f_SH, a->f_QL, a->f_QI, a->f_U, a->f_V, a->f_A})) {
+            rc = dispatch_bwd_v2(d, p, wt, (hipStream_t)stream, v2_pick("SPC_V2_K3", d->n_cols, d->nL));
+            if (rc <= 0) return rc;
+            p.d = make_dims(d, cb);
+        }
+    }
     const unsigned grid = (unsigned)((d->n_cols + cb - 1) / cb);
     if (cons)
         hipLaunchKernelGGL(k_backward_cons<T>, dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);

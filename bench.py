@@ -158,6 +158,49 @@ def verify(fplan, bplan, ref_f, ref_b, n_ref, factor, dt):
                        "f_thl_max_rel_err": rel, "failures": bad}
 
 
+def dropin_rate(eng, n_les=1024, steps=30, warmup=3, per_les_steps=3):
+    """Column-exchanges/s THROUGH THE DROP-IN API: driver.Coupler.step (gather -> set_les_forcings -> LES -> profiles
+    -> set_gcm_tendencies) on the in-process synthetic GCM/LES pair, host buffers in, host buffers out every step
+    (PCIe both ways), with the time spent inside the model objects' own methods subtracted.  Two transports:
+    the optional batched model protocol (one call per variable for all columns) and the reference's per-LES calls."""
+    import torch
+    from sp_coupler_amd import models, spcpl
+    from sp_coupler_amd.driver import Coupler
+    spcpl.set_engine(eng)
+    out = {"n_cols": n_les, "levels": "91<->160", "unit": "column-exchanges/s",
+           "note": "wall time of Coupler.step minus time inside model methods; includes H2D/D2H of every step"}
+    gcm, ens = models.make_batched_models(n_les, nG=91, nL=160, seed=3)
+    cpl = Coupler(gcm, ens)
+    for _ in range(warmup):
+        cpl.step()
+    torch.cuda.synchronize()
+    models.model_seconds = 0.0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        cpl.step()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    out["batched_protocol"] = {"value": n_les * steps / (wall - models.model_seconds), "steps": steps,
+                               "ms_per_step_coupler": (wall - models.model_seconds) / steps * 1e3,
+                               "ms_per_step_models": models.model_seconds / steps * 1e3}
+    # the reference's transport: ~20 getter / setter calls per column per step (spcpl.py:341-347, 535-542, 748-766)
+    gcm2, ens2 = models.make_batched_models(n_les, nG=91, nL=160, seed=3)
+    gcm2.__class__ = models.SyntheticGCM
+    cpl2 = Coupler(gcm2, [ens2[i] for i in range(n_les)])
+    cpl2.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(per_les_steps):
+        cpl2.step()
+    torch.cuda.synchronize()
+    wall2 = time.perf_counter() - t0
+    out["per_les_protocol"] = {"value": n_les * per_les_steps / wall2, "steps": per_les_steps,
+                               "ms_per_step": wall2 / per_les_steps * 1e3,
+                               "note": "model time NOT subtracted (the per-column Python calls ARE the cost)"}
+    spcpl.set_engine(None)
+    return out
+
+
 class Workload:
     """ROTATE batches of one configuration resident in HBM + the exchange plans bench.py times."""
 
@@ -214,6 +257,7 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--no-cpu-multicore", action="store_true", help="skip the all-cores cpu_baseline extra")
     ap.add_argument("--no-small-batch", action="store_true", help="skip the config-2 extra at N=1")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in API (Coupler.step) rate at N=1")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N>1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--device", type=int, default=None, help="force this HIP device for every rank (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
@@ -325,6 +369,13 @@ def main():
                  "k3_algorithmic_bytes_per_launch": a2["k3_launch"] * n2}
         del w2
 
+    dropin = None
+    if world == 1 and not args.no_dropin:
+        try:
+            dropin = dropin_rate(eng)
+        except Exception as e:                       # a reported extra, never fatal for the headline
+            dropin = {"error": repr(e)}
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -376,6 +427,9 @@ def main():
                                         "algorithmic_bytes_per_launch": ab["k3_launch"] * n_cols}}
     if small is not None:
         out["small_batch"] = small
+    if dropin is not None:
+        out["dropin"] = dropin
+        out["dropin_value"] = dropin.get("batched_protocol", {}).get("value")
     out["verified"] = None
     if args.cpu_seconds > 0 and world == 1:
         gcm, zf, zh, prof = wl.host0

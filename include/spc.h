@@ -171,6 +171,11 @@ int spc_stream_copy(void *dst, const void *src, int64_t bytes, void *stream);
  * PMC counters on a known byte count in this path's own access pattern.                           */
 int spc_stream_copy_f64(void *dst, const void *src, int64_t bytes, void *stream);
 
+/* Bandwidth probe for roofline reporting (tools/bwprobe.py): n_read read streams and n_write write streams of
+ * bytes_per_stream bytes each (stream r at src + r*bytes_per_stream, w at dst + w*bytes_per_stream), 16 B/lane,
+ * `grid` workgroups of 256 threads.  Instantiated mixes: 1:1, 1:0, 0:1, 2:1, 4:2, 8:0, 0:7, 14:7, 16:7.      */
+int spc_stream_probe(int n_read, int n_write, void *dst, const void *src, int64_t bytes_per_stream, int grid, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,6 +82,7 @@ PROTOTYPES = {
     "spc_pick_cols_per_block": (ctypes.c_int, [ctypes.POINTER(Dims), ctypes.c_int]),
     "spc_stream_copy": (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "spc_stream_copy_f64": (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "spc_stream_probe": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, c_int64, ctypes.c_int, c_void_p]),
 }
 
 _lib = None

@@ -31,6 +31,19 @@
 
 #pragma clang fp contract(off)
 
+// Diagnostic builds only (never the shipped library; tools/exp_variants.sh): apportion kernel time.
+//   -DSPC_EXP=1  every division becomes a multiplication by v_rcp_f64 (NOT bit-exact)
+//   -DSPC_EXP=3  as 1, and pow() becomes a multiplication
+//   -DSPC_EXP=2  as 3, and the searches are replaced by a constant index (memory + LDS traffic only)
+#ifndef SPC_EXP
+#define SPC_EXP 0
+#endif
+#if SPC_EXP
+#define SPC_DIV(a, b) ((a) * __builtin_amdgcn_rcp(b))
+#else
+#define SPC_DIV(a, b) ((a) / (b))
+#endif
+
 namespace {
 
 #ifndef SPC_BLOCK
@@ -58,7 +71,11 @@ template <typename T> struct K {
 __device__ __forceinline__ double spc_pow(double x, double y) { return exp(y * log(x)); }
 __device__ __forceinline__ float spc_pow(float x, float y) { return expf(y * logf(x)); }
 #else
+#if SPC_EXP >= 2
+__device__ __forceinline__ double spc_pow(double x, double y) { return x * y; }
+#else
 __device__ __forceinline__ double spc_pow(double x, double y) { return pow(x, y); }
+#endif
 __device__ __forceinline__ float spc_pow(float x, float y) { return powf(x, y); }
 #endif
 
@@ -99,9 +116,9 @@ template <int WT, typename T> __device__ __forceinline__ void stg(T *q, T v)
 // and bit-parity of the u/v/qt/ql forcings and of all tendencies depends on it.  (Tried and measured
 // slower on gfx950: RN(1/y) shared by the 5-7 slopes of a level + two FMA Newton steps + v_div_fixup;
 // the magnitude-window checks it needs cost more than hipcc's v_div_scale/v_rcp/v_div_fmas expansion.)
-template <typename T> __device__ __forceinline__ T div_grav(T x) { return x / K<T>::grav; }
-template <typename T> __device__ __forceinline__ T div_cp(T x) { return x / K<T>::cp; }
-template <typename T> __device__ __forceinline__ T div_pref0(T x) { return x / K<T>::pref0; }
+template <typename T> __device__ __forceinline__ T div_grav(T x) { return SPC_DIV(x, K<T>::grav); }
+template <typename T> __device__ __forceinline__ T div_cp(T x) { return SPC_DIV(x, K<T>::cp); }
+template <typename T> __device__ __forceinline__ T div_pref0(T x) { return SPC_DIV(x, K<T>::pref0); }
 
 // numpy NaN-aware "a < b" used by searchsorted (NaN sorts to the end)
 template <typename T> __device__ __forceinline__ bool np_lt(T a, T b) { return a < b || (b != b && a == a); }
@@ -133,6 +150,9 @@ template <typename T> __device__ __forceinline__ int ss_left_neg(const T *a, int
 // largest power of two <= n, so every lane runs the same floor(log2 n)+1 steps (no divergence).
 template <typename T> __device__ __forceinline__ int upper_count(const T *xp, int n, int p2, T x)
 {
+#if SPC_EXP == 2
+    return ((int)(x * T(0.001)) & 15) + 1;
+#endif
     int pos = 0;
     for (int s = p2; s > 0; s >>= 1) {
         const int t = pos + s;
@@ -224,7 +244,7 @@ template <int NF, typename T> __device__ __forceinline__ void interp_fields(cons
     bool any_nan = false;
 #pragma unroll
     for (int k = 0; k < NF; ++k) {
-        slope[k] = (f1[k] - f0[k]) / dx;
+        slope[k] = SPC_DIV(f1[k] - f0[k], dx);
         r[k] = slope[k] * t0 + f0[k];
         any_nan |= (r[k] != r[k]);
     }
@@ -892,6 +912,28 @@ __global__ __launch_bounds__(BLOCK) void k_copy16(uint4 *dst, const uint4 *src, 
         dst[i] = src[i];
 }
 
+// Bandwidth probes (tools/bwprobe.py): what this box's HBM delivers for a pure read, a pure write and a
+// read:write mix in MANY concurrent streams like the coupling kernels' (NS separate arrays advancing together),
+// so that the kernels' achieved GB/s can be set against the ceiling of their own access pattern.
+// mode 0: copy, 1: read only (sum), 2: write only; NR read streams + NW write streams of `n16` uint4 each.
+template <int NR, int NW>
+__global__ __launch_bounds__(BLOCK) void k_probe(uint4 *dst, const uint4 *src, int64_t n16, int64_t stride16, unsigned *sink)
+{
+    unsigned acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n16; i += (int64_t)gridDim.x * BLOCK) {
+        uint4 v[NR > 0 ? NR : 1];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) v[r] = src[r * stride16 + i];
+        uint4 w = {1u, 2u, 3u, (unsigned)i};
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { w.x ^= v[r].x; w.y += v[r].y; w.z ^= v[r].z; w.w += v[r].w; }
+#pragma unroll
+        for (int q = 0; q < NW; ++q) dst[q * stride16 + i] = w;
+        if (NW == 0) acc += w.x + w.y + w.z + w.w;
+    }
+    if (NW == 0 && acc == 0x12345678u) *sink = acc;      // keeps the loads alive; practically never true
+}
+
 // 8 B/lane streaming copy: the access width of the coupling kernels (PMC calibration, tools/pmc_summary.py)
 __global__ __launch_bounds__(BLOCK) void k_copy8(double *dst, const double *src, int64_t n8)
 {
@@ -1068,14 +1110,20 @@ bool aligned16(std::initializer_list<const void *> ptrs)
 
 struct V2Choice { int cb, block; };
 
-// measured choice per batch size (profiles/r02_*): small launches want many small workgroups, large ones longer slabs
-V2Choice v2_pick(const char *env, int64_t n_cols, int nL)
+// Measured choice per pass and batch size (same-box A/B of every variant against the first-generation kernels,
+// profiles/r02_kbench_variants.log): the second-generation K1 wins 2-4 % between ~6k and ~65k columns (the
+// per-GPU shard sizes of configs 3-4), the 8-column K3 wins 7 % from ~200k columns; elsewhere the first-generation
+// kernels are as fast or faster and stay in use (cb = 0).  SPC_V2_K1 / SPC_V2_K3 = "cb,block" force a variant.
+V2Choice v2_pick(const char *env, int pass, int64_t n_cols, int nG, int nL)
 {
     V2Choice c;
     if (env_pair(env, &c.cb, &c.block)) return c;
-    if (nL == 512) return V2Choice{2, 512};
-    if (n_cols <= 2048) return V2Choice{2, 192};
-    return V2Choice{4, 256};
+    c.cb = 0; c.block = 0;
+    if (nG == 91 && nL == 160) {
+        if (pass == 0 && n_cols >= 6000 && n_cols <= 65000) c = V2Choice{2, 192};
+        if (pass == 1 && n_cols >= 200000) c = V2Choice{8, 512};
+    }
+    return c;
 }
 
 template <int NG, int NL, int CB, int BLOCK_>
@@ -1116,6 +1164,7 @@ int launch_bwd_v2(const spc_dims *d, BwdP<double> &p, int wt, hipStream_t stream
 
 int dispatch_fwd_v2(const spc_dims *d, FwdP<double, false> &p, int wt, hipStream_t stream, V2Choice c)
 {
+    if (c.cb == 0) return 1;
 #define X(NG_, NL_, CB_, BL_) \
     if (d->nG == NG_ && d->nL == NL_ && c.cb == CB_ && c.block == BL_) return launch_fwd_v2<NG_, NL_, CB_, BL_>(d, p, wt, stream);
     SPC_V2_VARIANTS(X)
@@ -1125,6 +1174,7 @@ int dispatch_fwd_v2(const spc_dims *d, FwdP<double, false> &p, int wt, hipStream
 
 int dispatch_bwd_v2(const spc_dims *d, BwdP<double> &p, int wt, hipStream_t stream, V2Choice c)
 {
+    if (c.cb == 0) return 1;
 #define X(NG_, NL_, CB_, BL_) \
     if (d->nG == NG_ && d->nL == NL_ && c.cb == CB_ && c.block == BL_) return launch_bwd_v2<NG_, NL_, CB_, BL_>(d, p, wt, stream);
     SPC_V2_VARIANTS(X)
@@ -1195,7 +1245,7 @@ template <typename T> int forward_impl(const spc_dims *d, const spc_forward_args
             if (geo != 0 && d->cols_per_block == 0 && env_int("SPC_V2", 1) &&
                 aligned16({a->U, a->V, a->T, a->SH, a->QL, a->QI, a->Pf, a->Zgfull, a->zf, a->zh, a->u_d, a->v_d, a->thl_d, a->qt_d,
                            a->ql_d, a->f_u, a->f_v, a->f_thl, a->f_qt, a->f_ql, a->ql_ref})) {
-                rc = dispatch_fwd_v2(d, p, wt, (hipStream_t)stream, v2_pick("SPC_V2_K1", d->n_cols, d->nL));
+                rc = dispatch_fwd_v2(d, p, wt, (hipStream_t)stream, v2_pick("SPC_V2_K1", 0, d->n_cols, d->nG, d->nL));
                 if (rc <= 0) return rc;
                 fill(p);
             }
@@ -1265,7 +1315,7 @@ template <typename T> int backward_impl(const spc_dims *d, const spc_backward_ar
         if (!cons && geo != 0 && d->cols_per_block == 0 && env_int("SPC_V2", 1) &&
             aligned16({a->T, a->SH, a->QL, a->QI, a->U, a->V, a->A, a->Zf, a->Zgfull, a->zf, a->t_d, a->qt_d, a->ql_d, a->ql_ice_d,
                        a->u_d, a->v_d, a->f_T, a->f_SH, a->f_QL, a->f_QI, a->f_U, a->f_V, a->f_A})) {
-            rc = dispatch_bwd_v2(d, p, wt, (hipStream_t)stream, v2_pick("SPC_V2_K3", d->n_cols, d->nL));
+            rc = dispatch_bwd_v2(d, p, wt, (hipStream_t)stream, v2_pick("SPC_V2_K3", 1, d->n_cols, d->nG, d->nL));
             if (rc <= 0) return rc;
             p.d = make_dims(d, cb);
         }
@@ -1398,6 +1448,22 @@ int spc_stream_copy(void *dst, const void *src, int64_t bytes, void *stream)
     if (bytes == 0) return SPC_OK;
     hipLaunchKernelGGL(k_copy16, dim3(copy_grid()), dim3(BLOCK), 0, (hipStream_t)stream, (uint4 *)dst, (const uint4 *)src, bytes / 16);
     return launch_status("k_copy16");
+}
+
+int spc_stream_probe(int n_read, int n_write, void *dst, const void *src, int64_t bytes_per_stream, int grid, void *stream)
+{
+    if (bytes_per_stream <= 0 || (bytes_per_stream & 15) || !dst || !src || grid <= 0)
+        return fail(SPC_ERR_INVALID_ARGUMENT, "%sstream_probe: bad arguments");
+    const int64_t n16 = bytes_per_stream / 16;
+    unsigned *sink = (unsigned *)dst;
+#define PROBE(NR_, NW_) \
+    if (n_read == NR_ && n_write == NW_) { \
+        hipLaunchKernelGGL((k_probe<NR_, NW_>), dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (uint4 *)dst, (const uint4 *)src, n16, n16, sink); \
+        return launch_status("k_probe"); \
+    }
+    PROBE(1, 1) PROBE(1, 0) PROBE(0, 1) PROBE(2, 1) PROBE(14, 7) PROBE(16, 7) PROBE(8, 0) PROBE(0, 7) PROBE(4, 2)
+#undef PROBE
+    return fail(SPC_ERR_UNSUPPORTED, "%sstream_probe: stream mix not instantiated");
 }
 
 int spc_stream_copy_f64(void *dst, const void *src, int64_t bytes, void *stream)

@@ -13,7 +13,8 @@ from .models import RequestsPool
 class Coupler:
     def __init__(self, gcm, les_models, cplsurf=False, les_forcing_factor=1.0, gcm_forcing_factor=1.0,
                  conservative_coarsening=False, qt_forcing="sp", les_spinup=0, output_column_indices=None, write=False):
-        self.gcm, self.les_models = gcm, list(les_models)
+        self.ensemble = spcpl._is_ensemble(les_models)          # LES side offers the batched protocol (models.py)
+        self.gcm, self.les_models = gcm, (les_models if self.ensemble else list(les_models))
         self.cplsurf = cplsurf                                   # splib/splib.py:67
         self.les_forcing_factor = les_forcing_factor             # splib/splib.py:57
         self.gcm_forcing_factor = gcm_forcing_factor             # splib/splib.py:46
@@ -25,9 +26,10 @@ class Coupler:
         self.firststep = True
         self.profiles = {}
         self.timing_rows = []                                    # rows of timing.txt (splib/splib.py:340-343)
-        for les in self.les_models:
-            if not hasattr(les, "zf_cache"):
-                les.zh_cache, les.zf_cache = les.get_zh(), les.get_zf()    # splib/splib.py:152-153
+        if not self.ensemble:
+            for les in self.les_models:
+                if not hasattr(les, "zf_cache"):
+                    les.zh_cache, les.zf_cache = les.get_zh(), les.get_zf()    # splib/splib.py:152-153
 
     def initialize_output(self, les_spinup_steps=1):
         """splib.initialize (splib/splib.py:192-193): the spifs record the FIRST step writes into is opened at
@@ -37,6 +39,12 @@ class Coupler:
 
     # splib/splib.py:554-594 (async branch): evolve every LES, then fetch its slab means
     def step_les_models(self, model_time, offset=0):
+        if self.ensemble:                       # one evolve call and one getter round for ALL columns
+            t0 = time.time()
+            self.les_models.evolve_model_batched(model_time + offset)
+            wall = time.time() - t0
+            diag = self.conservative_coarsening or (self.write and spcpl.writer is not None)
+            return [wall], spcpl.get_les_profiles_batched(self.les_models, True, diagnostics=diag)
         pool = RequestsPool()
         reqs, profile_reqs = [], {}
         for les in self.les_models:
@@ -103,11 +111,12 @@ class Coupler:
 
     # splib/splib.py:355-402 (forcings with dt = spinup length, no GCM tendencies)
     def step_spinup(self, spinup_length, les_spinup_forcing_factor=1.0):
-        if not self.les_models:
+        if not len(self.les_models):
             return
-        if any(getattr(les, "_spc_batch", None) is None for les in self.les_models):   # splib.py:196 gathered at init
+        probe = [self.les_models] if self.ensemble else self.les_models
+        if any(getattr(les, "_spc_batch", None) is None for les in probe):   # splib.py:196 gathered at init
             spcpl.gather_gcm_data(self.gcm, self.les_models, self.cplsurf, write=self.write)
-        t_les = self.les_models[0].get_model_time()
+        t_les = self.les_models.model_time if self.ensemble else self.les_models[0].get_model_time()
         pool = RequestsPool()
         for req in spcpl.set_les_forcings_batched(self.les_models, self.gcm, True, self.firststep, self.profiles,
                                                   dt_gcm=spinup_length, factor=les_spinup_forcing_factor,

@@ -274,3 +274,252 @@ def make_models(n_les, npoints=None, nG=91, nL=160, seed=1):
         gcm.set_mask(i)
         les_models.append(les)
     return gcm, les_models
+
+
+# ---------------------------------------------------------------------------------------------
+# Batched model protocol (optional).  The reference talks to every LES through
+# ~20 RPCs per column per step (splib/spcpl.py:341-347, 748-766) and to the GCM through 7 per column
+# (spcpl.py:535-542).  A model object MAY additionally offer the batched calls below; sp_coupler_amd.spcpl uses
+# them when present (one call per variable for ALL columns, writing straight into / reading straight from the
+# coupler's pinned transfer buffers) and falls back to the reference's per-column calls otherwise.
+#   GCM   supports_out = True           get_profile_fields(var, cols, out=ndarray), get_surface_field(..., out=)
+#         set_profile_tendencies(var, grid_indices, values[n x nG])
+#   LES   an ENSEMBLE object passed as `les_models` with batched = True, list-like over per-column LES objects:
+#         grid_indices, zf_cache, zh_cache, get_profiles_batched(keys, out), get_cloudfraction_batched(indices, out),
+#         set_forcings_batched(**arrays), evolve_model_batched(t)
+# ---------------------------------------------------------------------------------------------
+import time as _time
+
+#: seconds spent INSIDE model methods of the batched stand-ins (bench.py subtracts it: `dropin` rate excludes model time)
+model_seconds = 0.0
+
+
+def _timed(fn):
+    def wrapper(*a, **kw):
+        global model_seconds
+        t0 = _time.perf_counter()
+        try:
+            return fn(*a, **kw)
+        finally:
+            model_seconds += _time.perf_counter() - t0
+    wrapper.__name__ = fn.__name__
+    wrapper.__doc__ = fn.__doc__
+    return wrapper
+
+
+class BatchedSyntheticGCM(SyntheticGCM):
+    """SyntheticGCM + the optional batched protocol (out= getters, one tendency setter per variable)."""
+
+    supports_out = True
+
+    @_timed
+    def get_profile_fields(self, var, cols, out=None):
+        idx = numpy.asarray(cols, dtype=numpy.int64)
+        if out is None:
+            return self.state[var][idx]
+        return numpy.take(self.state[var], idx, axis=0, out=out)
+
+    get_surface_field = get_profile_fields
+
+    @_timed
+    def set_profile_tendencies(self, var, grid_indices, values):
+        """all SP columns at once: values [n x nG] (a view into the coupler's transfer buffer: copied here)"""
+        self.tendencies[var] = (numpy.asarray(grid_indices, dtype=numpy.int64), numpy.array(values, dtype=numpy.float64))
+
+    @_timed
+    def evolve_model_from_cloud_scheme(self):
+        self.calls.append("from_cloud_scheme")
+        for var, t in self.tendencies.items():
+            if isinstance(t, tuple):
+                gi, f = t
+                f = numpy.where(numpy.isfinite(f), f, 0.0)
+                self.state[var][gi] = self.state[var][gi] + self.dt * f
+            else:
+                for g, f in t.items():
+                    f = numpy.where(numpy.isfinite(f), f, 0.0)
+                    self.state[var][g] = self.state[var][g] + self.dt * f
+        for k in ("SH", "QL", "QI", "A"):
+            numpy.clip(self.state[k], 0.0, None, out=self.state[k])
+        self.model_time += self.dt
+
+
+class _LESRow:
+    """Per-column face of an ensemble row: the reference's per-LES method names on row i of the ensemble arrays."""
+
+    support_async = True
+
+    def __init__(self, ens, i):
+        self._e, self._i = ens, i
+        self.grid_index = int(ens.grid_indices[i])
+        self.zf_cache, self.zh_cache = ens.zf_cache, ens.zh_cache
+        self.lat = self.lon = 0.0
+        self.received = []
+
+    def get_zf(self):
+        return self._e.zf_cache
+
+    def get_zh(self):
+        return self._e.zh_cache
+
+    def get_itot(self):
+        return 8
+
+    get_jtot = get_itot
+
+    def get_ktot(self):
+        return self._e.nL
+
+    def get_model_time(self):
+        return self._e.model_time
+
+    @property
+    def model_time(self):
+        return self._e.model_time
+
+    @property
+    def p(self):
+        return {k: v[self._i] for k, v in self._e.p.items()}
+
+    def get_cloudfraction(self, indices, return_request=False):
+        idx = numpy.clip(numpy.asarray(indices), 0, self._e.nL - 1)
+        return _ret(self._e.A_lev[self._i][idx], return_request)
+
+    def evolve_model(self, t, exactEnd=True):
+        self._e.evolve_model_batched(t)         # the ensemble advances as one; later rows find it already there
+        return ImmediateRequest(0.0)
+
+    def write_restart(self):
+        pass
+
+
+def _row_getter(key):
+    def get(self, return_request=False):
+        v = self._e.p[key][self._i]
+        return _ret(v.copy() if isinstance(v, numpy.ndarray) else float(v), return_request)
+    return get
+
+
+def _row_setter(name):
+    def set_(self, values, return_request=False):
+        v = numpy.asarray(getattr(values, "number", values), dtype=numpy.float64)
+        self._e.tend.setdefault(name, self._e._zeros_like_tend(name))[self._i] = v
+        self.received.append(name)
+        return _ret(None, return_request)
+    return set_
+
+
+for _m, _k in (("get_profile_U", "U"), ("get_profile_V", "V"), ("get_profile_THL", "THL"), ("get_profile_QT", "QT"),
+               ("get_profile_QL", "QL"), ("get_profile_QL_ice", "QL_ice"), ("get_profile_QR", "QR"), ("get_profile_T", "T"),
+               ("get_presf", "presf"), ("get_rhof", "Rhof"), ("get_rhobf", "Rhobf"), ("get_surface_pressure", "PS"),
+               ("get_rain", "Rain")):
+    setattr(_LESRow, _m, _row_getter(_k))
+for _m, _k in (("set_tendency_U", "U"), ("set_tendency_V", "V"), ("set_tendency_THL", "THL"), ("set_tendency_QT", "QT"),
+               ("set_tendency_QL", "QL"), ("set_tendency_surface_pressure", "PS"), ("set_ref_profile_QL", "QL_ref"),
+               ("set_z0m_surf", "z0m"), ("set_z0h_surf", "z0h"), ("set_wt_surf", "wt"), ("set_wq_surf", "wq")):
+    setattr(_LESRow, _m, _row_setter(_k))
+
+# request-dict keys of set_les_forcings (splib/spcpl.py:383-385) -> tendency slots of the stand-in
+_FORCING_SLOT = {"U": "U", "V": "V", "THL": "THL", "QT": "QT", "SP": "PS", "QL": "QL", "QLp": "QL_ref",
+                 "Z0M_surf": "z0m", "Z0H_surf": "z0h", "WT_surf": "wt", "WQ_surf": "wq"}
+
+
+class SyntheticLESEnsemble:
+    """All DALES stand-ins of a run as [n x nL] arrays: same arithmetic as n ``SyntheticLES`` objects, with the
+    optional batched protocol.  List-like over per-column faces (``_LESRow``), so the reference's per-LES loops
+    work on it unchanged."""
+
+    batched = True
+
+    def __init__(self, grid_indices, zf, zh, prof):
+        self.grid_indices = numpy.asarray(grid_indices, dtype=numpy.int64)
+        self.n = len(self.grid_indices)
+        self.zf_cache, self.zh_cache = zf, zh
+        self.nL = zf.shape[-1]
+        self.p = {k: numpy.array(v, dtype=numpy.float64) for k, v in prof.items() if k not in ("A", "rain_last")}
+        self.A_lev = numpy.clip(self.p["QL"] * 2e3, 0.0, 1.0)
+        self.model_time = 0.0
+        self.tend = {}
+        self._rows = [None] * self.n
+
+    @classmethod
+    def from_models(cls, les_list):
+        """stack existing SyntheticLES objects (same state, same evolution)"""
+        keys = les_list[0].p.keys()
+        prof = {k: numpy.stack([numpy.asarray(m.p[k]) for m in les_list]) for k in keys}
+        return cls([m.grid_index for m in les_list], les_list[0].zf, les_list[0].zh, prof)
+
+    @classmethod
+    def for_gcm(cls, gcm, grid_indices, nL=160, seed=0):
+        """fresh ensemble for the given GCM columns (one vectorised generator call)"""
+        gi = numpy.asarray(grid_indices, dtype=numpy.int64)
+        sub = {k: v[gi] for k, v in gcm.state.items()}
+        zf, zh, prof = synthetic.make_les_profiles(sub, nL, seed)
+        for i in gi:
+            gcm.set_mask(i)
+        return cls(gi, zf, zh, prof)
+
+    # -- list-like ---------------------------------------------------------------------------------
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(self.n))]
+        if self._rows[i] is None:
+            self._rows[i] = _LESRow(self, i)
+        return self._rows[i]
+
+    def __iter__(self):
+        return (self[i] for i in range(self.n))
+
+    def _zeros_like_tend(self, name):
+        return numpy.zeros((self.n, self.nL)) if name in ("U", "V", "THL", "QT", "QL", "QL_ref") else numpy.zeros(self.n)
+
+    # -- batched protocol --------------------------------------------------------------------------
+    @_timed
+    def get_profiles_batched(self, keys, out):
+        """out[key][...] = slab means of ALL columns ([n x nL], or [n] for PS / Rain); `out` arrays are views
+        into the coupler's pinned upload buffer"""
+        for k in keys:
+            numpy.copyto(out[k], self.p[k])
+
+    @_timed
+    def get_cloudfraction_batched(self, indices, out):
+        """les.get_cloudfraction(indices) for every column: indices [n x nG] -> out [n x nG]"""
+        idx = numpy.clip(indices, 0, self.nL - 1)
+        numpy.copyto(out, numpy.take_along_axis(self.A_lev, idx, axis=1))
+
+    @_timed
+    def set_forcings_batched(self, **arrays):
+        """the setters of spcpl.py:341-347 / 361-364 for all columns, keyed like the request dict of
+        set_les_forcings (U, V, THL, QT, SP, QL, QLp, Z0M_surf, Z0H_surf, WT_surf, WQ_surf); values are views
+        into the coupler's download buffer and are copied here"""
+        for k, v in arrays.items():
+            self.tend[_FORCING_SLOT[k]] = numpy.array(v, dtype=numpy.float64)
+
+    @_timed
+    def evolve_model_batched(self, t):
+        dt = float(t) - self.model_time
+        if dt <= 0:
+            return
+        p = self.p
+        for key in ("U", "V", "THL", "QT", "QL"):
+            if key in self.tend:
+                p[key] = p[key] + dt * self.tend[key]
+        if "PS" in self.tend:
+            p["PS"] = p["PS"] + dt * self.tend["PS"]
+        p["QL"] = numpy.clip(p["QL"], 0.0, None)
+        p["QL_ice"] = numpy.minimum(p["QL_ice"], p["QL"])
+        p["T"] = p["THL"] * (p["presf"] / 1e5) ** (287.04 / 1004.) + 2.53e6 * p["QL"] / 1004.
+        p["Rain"] = p["Rain"] + 1e-6 * dt
+        self.A_lev = numpy.clip(p["QL"] * 2e3, 0.0, 1.0)
+        self.model_time = float(t)
+
+
+def make_batched_models(n_les, npoints=None, nG=91, nL=160, seed=1):
+    """(BatchedSyntheticGCM, SyntheticLESEnsemble) with LES in grid columns 1..n_les -- the fast construction for
+    large column counts (one vectorised generator call instead of n_les)."""
+    npoints = npoints or (n_les + 4)
+    gcm = BatchedSyntheticGCM(npoints, nG, seed)
+    ens = SyntheticLESEnsemble.for_gcm(gcm, numpy.arange(1, n_les + 1), nL, seed)
+    return gcm, ens

@@ -87,58 +87,206 @@ def _result(x):
     return x.result() if hasattr(x, "result") and callable(x.result) else x
 
 
-class ColumnBatch:
-    """All SP columns of one GCM step, resident in HBM as [n_cols x n_lev] tensors."""
+class Arena:
+    """Named arrays packed into ONE pinned host buffer and ONE device buffer, so that a whole group of inputs
+    (or results) crosses PCIe in a single copy.  ``h[name]`` / ``hn[name]`` are the host views (torch / NumPy),
+    ``d[name]`` the device views; every array starts 256-B aligned (the 16-B accesses of the compile-time-geometry
+    kernels need aligned bases).  With a CPU "device" (the test-only oracle engine) host and device are one buffer."""
 
-    def __init__(self, engine, les_models, gcm_host, surf_host, extra_cols):
+    ALIGN = 256
+
+    def __init__(self, device, specs):
+        self.device = torch.device(device)
+        off, lay = 0, []
+        for name, shape, dtype in specs:
+            nbytes = int(numpy.prod(shape, dtype=numpy.int64)) * torch.empty((), dtype=dtype).element_size()
+            lay.append((name, tuple(shape), dtype, off, nbytes))
+            off += -(-nbytes // self.ALIGN) * self.ALIGN
+        self.nbytes = off
+        on_gpu = self.device.type == "cuda"
+        self.host = torch.empty(max(off, 1), dtype=torch.uint8, pin_memory=on_gpu)
+        self.dev = torch.empty(max(off, 1), dtype=torch.uint8, device=self.device) if on_gpu else self.host
+        self.h, self.d, self.hn, self.end = {}, {}, {}, {}
+        for name, shape, dtype, o, nb in lay:
+            self.h[name] = self.host[o:o + nb].view(dtype).view(shape)
+            self.d[name] = self.dev[o:o + nb].view(dtype).view(shape)
+            self.hn[name] = self.h[name].numpy()
+            self.end[name] = o + nb
+
+    def upload(self, upto=None):
+        """host -> device (one async copy on the current stream; later kernels on that stream are ordered after it)"""
+        if self.dev is not self.host:
+            n = self.nbytes if upto is None else self.end[upto]
+            self.dev[:n].copy_(self.host[:n], non_blocking=True)
+
+    def download(self, upto=None):
+        """device -> host of the arrays up to and including ``upto`` (default all), then wait for it"""
+        if self.dev is not self.host:
+            n = self.nbytes if upto is None else self.end[upto]
+            self.host[:n].copy_(self.dev[:n], non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()
+
+
+_F64, _I32 = torch.float64, torch.int32
+#: LES slab means the kernels consume (forward: spcpl.py:310-315; backward: spcpl.py:393-411); scalars last
+_LES_IN_LEVELS = ("U", "V", "THL", "QT", "QL", "T", "QL_ice")
+_LES_DIAG_LEVELS = ("Rhobf", "presf", "Rhof", "QR")          # conservative coarsening / spifs diagnostics only
+_LES_IN_SCALARS = ("PS", "Rain", "rain_last")
+
+
+class StepBuffers:
+    """Transfer buffers and launch plans of one batch geometry, allocated ONCE and reused every step (pinned
+    allocations cost milliseconds): GCM state up, LES slab means up, forcings down, tendencies down."""
+
+    def __init__(self, engine, n, n_total, nG, nL, with_surf):
+        self.engine, self.n, self.n_total, self.nG, self.nL = engine, n, n_total, nG, nL
+        dev, dt = engine.device, engine.dtype
+        g = [(v, (n_total, nG + 1 if v in ("Phalf", "Zghalf") else nG), dt) for v in gcm_vars]
+        if with_surf:
+            g += [(v, (n_total,), dt) for v in surf_vars]
+        self.gcm_in = Arena(dev, g)
+        self.les_in = Arena(dev, [(k, (n, nL), dt) for k in _LES_IN_LEVELS] + [("A", (n, nG), dt)]
+                            + [(k, (n,), dt) for k in _LES_IN_SCALARS] + [(k, (n, nL), dt) for k in _LES_DIAG_LEVELS])
+        # what the 7 LES setters + get_cloudfraction need comes first ("core": downloaded every step); heights
+        # and surface fluxes follow and cross PCIe only when somebody asks for them
+        self.fwd_out = Arena(dev, [(k, (n, nL), dt) for k in ("f_u", "f_v", "f_thl", "f_qt", "f_ql", "ql_ref")]
+                             + [("f_ps", (n,), dt), ("idx", (n, nG), _I32)]
+                             + [("wthl", (n,), dt), ("wqt", (n,), dt), ("Zf", (n, nG), dt), ("Zh", (n, nG + 1), dt),
+                                ("Tv", (n, nG), dt), ("THL", (n, nG), dt), ("QT", (n, nG), dt)]
+                             + [(k, (n, nL), dt) for k in ("u", "v", "thl", "qt")] + [("ps", (n,), dt)])
+        self.bwd_out = Arena(dev, [(k, (n, nG), dt) for k in ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A")]
+                             + [("start_index", (n,), _I32)])
+        self.plans = {}
+        self.grid_key = None
+        self.zf = self.zh = self.zf_host = self.zh_host = None
+
+    def set_grid(self, zf_host, zh_host):
+        key = (zf_host.shape, zf_host.tobytes(), zh_host.tobytes()) if zf_host.size <= 4096 else None
+        if key is None or key != self.grid_key:
+            dev, dt = self.engine.device, self.engine.dtype
+            self.zf_host, self.zh_host = zf_host, zh_host
+            self.zf = torch.from_numpy(numpy.ascontiguousarray(zf_host)).to(dev, dt)
+            self.zh = torch.from_numpy(numpy.ascontiguousarray(zh_host)).to(dev, dt)
+            self.grid_key = key
+            self.plans = {}
+
+
+_buffers = {}
+
+
+def _get_buffers(engine, n, n_total, nG, nL, with_surf):
+    key = (id(engine), n, n_total, nG, nL, bool(with_surf))
+    b = _buffers.get(key)
+    if b is None:
+        if len(_buffers) >= 4:      # a run has one geometry (plus spin-up variants): do not hoard pinned memory
+            _buffers.clear()
+        b = _buffers[key] = StepBuffers(engine, n, n_total, nG, nL, with_surf)
+    return b
+
+
+def _is_ensemble(les_models):
+    """the optional batched LES protocol (sp_coupler_amd.models docstring)"""
+    return bool(getattr(les_models, "batched", False))
+
+
+class ColumnBatch:
+    """All SP columns of one GCM step, resident in HBM as [n_cols x n_lev] tensors (views into the step's
+    transfer buffers: ONE host->device copy for the whole GCM state, one for the LES slab means)."""
+
+    def __init__(self, engine, les_models, gcm, cols, extra_cols, couple_surface):
         self.engine = engine
-        self.les_models = list(les_models)
+        self.ens = les_models if _is_ensemble(les_models) else None
+        self.les_models = les_models if self.ens is not None else list(les_models)
         self.n = len(self.les_models)
-        self.row = {id(les): i for i, les in enumerate(self.les_models)}
+        self.row = None if self.ens is not None else {id(les): i for i, les in enumerate(self.les_models)}
         self.extra_cols = list(extra_cols)
-        self.gcm_host = gcm_host          # dict var -> ndarray [n_total x n], rows n.. are the extra columns
-        self.surf_host = surf_host
-        dev = engine.device
-        self.gcm = {k: torch.from_numpy(numpy.ascontiguousarray(v[:self.n])).to(dev, engine.dtype)
-                    for k, v in gcm_host.items()} if self.n else {}
-        for k, v in surf_host.items():
-            self.gcm[k] = torch.from_numpy(numpy.ascontiguousarray(v[:self.n])).to(dev, engine.dtype)
-        self.zf = self.zh = None
-        self.zf_host = self.zh_host = None
+        n_total = len(cols)
+        use_out = bool(getattr(gcm, "supports_out", False))
+        first = None
+        nL = self._les_levels()
+        nG = getattr(gcm, "ktot", None)
+        if nG is None:                                    # learn the level count from the first variable
+            first = _num(gcm.get_profile_fields(gcm_vars[0], cols))
+            nG = first.shape[1]
+        self.buf = b = _get_buffers(engine, self.n, n_total, int(nG), nL, couple_surface)
+        hn = b.gcm_in.hn
+        for v in gcm_vars:                                                    # spcpl.py:62-67
+            if v == gcm_vars[0] and first is not None:
+                numpy.copyto(hn[v], first)
+            elif use_out:
+                gcm.get_profile_fields(v, cols, out=hn[v])
+            else:
+                numpy.copyto(hn[v], _num(gcm.get_profile_fields(v, cols)))
+        if couple_surface:
+            for v in surf_vars:                                               # spcpl.py:69-75
+                if use_out:
+                    gcm.get_surface_field(v, cols, out=hn[v])
+                else:
+                    numpy.copyto(hn[v], _num(gcm.get_surface_field(v, cols)))
+        b.gcm_in.upload()
+        self.gcm_host = {v: hn[v] for v in gcm_vars}      # rows n.. are the extra output columns
+        self.surf_host = {v: hn[v] for v in surf_vars} if couple_surface else {}
+        n = self.n
+        self.gcm = {k: t[:n] for k, t in b.gcm_in.d.items()}
         self.profiles = {}                # id(les) -> profile dict (values or async requests)
         self.profile_generation = 0
         self.fwd = None                   # host results of the last forward launch
         self.fwd_key = None
         self.bwd = None
         self.bwd_key = None
+        self.dev_prof = None              # device views of the LES slab means uploaded for this step
         if self.n:
             self._pack_les_grid()
+
+    def _les_levels(self):
+        if not len(self.les_models):
+            return 1
+        z = self.ens.zf_cache if self.ens is not None else self.les_models[0].zf_cache
+        return int(_num(z).shape[-1])
 
     def _pack_les_grid(self):
         """les.zf_cache / les.zh_cache (splib/splib.py:152-153): one shared [nL] grid when all LES
         instances agree (the normal case), else [n x nL]."""
-        zfs = [_num(les.zf_cache) for les in self.les_models]
-        zhs = [_num(les.zh_cache) for les in self.les_models]
-        shared = all(z.shape == zfs[0].shape and numpy.array_equal(z, zfs[0]) for z in zfs) and \
-            all(numpy.array_equal(z, zhs[0]) for z in zhs)
-        self.zf_host = zfs[0] if shared else numpy.stack(zfs)
-        self.zh_host = zhs[0] if shared else numpy.stack(zhs)
-        dev, dt = self.engine.device, self.engine.dtype
-        self.zf = torch.from_numpy(numpy.ascontiguousarray(self.zf_host)).to(dev, dt)
-        self.zh = torch.from_numpy(numpy.ascontiguousarray(self.zh_host)).to(dev, dt)
+        if self.ens is not None:
+            zf_host, zh_host = _num(self.ens.zf_cache), _num(self.ens.zh_cache)
+        else:
+            zfs = [_num(les.zf_cache) for les in self.les_models]
+            zhs = [_num(les.zh_cache) for les in self.les_models]
+            shared = all(z is zfs[0] or (z.shape == zfs[0].shape and numpy.array_equal(z, zfs[0])) for z in zfs) and \
+                all(z is zhs[0] or numpy.array_equal(z, zhs[0]) for z in zhs)
+            zf_host = zfs[0] if shared else numpy.stack(zfs)
+            zh_host = zhs[0] if shared else numpy.stack(zhs)
+        self.buf.set_grid(zf_host, zh_host)
+        self.zf, self.zh, self.zf_host, self.zh_host = self.buf.zf, self.buf.zh, self.buf.zf_host, self.buf.zh_host
 
     def index_of(self, les):
+        if self.ens is not None:
+            return les._i
         return self.row[id(les)]
 
     # ---- LES slab means -> device -------------------------------------------------------------
     def stack_profiles(self, keys, source):
-        """source(les) -> dict; returns dict key -> device tensor ([n x nL], [n x nG] for A, [n] scalars)"""
+        """per-LES protocol: source(les) -> dict (values or async requests).  Rows are written straight into the
+        pinned upload buffer; ONE host->device copy for all keys.  Returns dict key -> device tensor."""
+        hn = self.buf.les_in.hn
         rows = [source(les) for les in self.les_models]
-        out = {}
         for k in keys:
-            arr = numpy.stack([_num(_result(r[k])) for r in rows])
-            out[k] = torch.from_numpy(numpy.ascontiguousarray(arr)).to(self.engine.device, self.engine.dtype)
-        return out
+            dst = hn[k]
+            for i, r in enumerate(rows):
+                dst[i] = _num(_result(r[k]))
+        self.buf.les_in.upload()
+        return {k: self.buf.les_in.d[k] for k in keys}
+
+    def upload_profiles(self, keys, arrays=None):
+        """batched protocol: ``arrays`` (dict key -> [n x ...]) are copied into the upload buffer unless they ARE its
+        views already (ensemble getters write there directly); one host->device copy."""
+        hn = self.buf.les_in.hn
+        if arrays is not None:
+            for k in keys:
+                if arrays[k] is not hn[k]:
+                    numpy.copyto(hn[k], _num(arrays[k]))
+        self.buf.les_in.upload()
+        return {k: self.buf.les_in.d[k] for k in keys}
 
 
 _current = None
@@ -150,6 +298,8 @@ def current_batch():
 
 def _batch_of(les):
     b = getattr(les, "_spc_batch", None)
+    if b is None and hasattr(les, "_e"):               # per-column face of an ensemble
+        b = getattr(les._e, "_spc_batch", None)
     if b is None:
         raise RuntimeError("gather_gcm_data() must be called before the per-les coupling functions")
     return b
@@ -160,37 +310,35 @@ def _batch_of(les):
 # ---------------------------------------------------------------------------------------------
 def gather_gcm_data(gcm, les_models, couple_surface, output_column_indices=None, write=True, attach_rows=False):
     """Pull all SP columns' profiles with ONE ``gcm.get_profile_fields`` call per variable (as the
-    reference does, spcpl.py:66) and pack them into HBM.  The reference then scatters rows onto the
-    ``les`` objects (spcpl.py:81-86); here each ``les`` gets a handle to the batch instead
-    (``attach_rows=True`` also sets the per-variable row views for code that reads ``les.T`` etc.)."""
+    reference does, spcpl.py:66) straight into the pinned upload buffer and send them to HBM in ONE copy.  The
+    reference then scatters rows onto the ``les`` objects (spcpl.py:81-86); here each ``les`` gets a handle to the
+    batch instead (``attach_rows=True`` also sets the per-variable row views for code that reads ``les.T`` etc.)."""
     global _current
     extra_cols = [] if output_column_indices is None else list(output_column_indices)
-    cols = [les.grid_index for les in les_models] + extra_cols
+    ens = les_models if _is_ensemble(les_models) else None
+    cols = (list(ens.grid_indices) if ens is not None else [les.grid_index for les in les_models]) + extra_cols
     start = time.time()
-    profile_data, surface_data = {}, {}
-    empty = not any(cols)                                                    # quirk kept: spcpl.py:63,71
-    for v in gcm_vars:
-        profile_data[v] = [] if empty else _num(gcm.get_profile_fields(v, cols))
-    if couple_surface:
-        for v in surf_vars:
-            surface_data[v] = [] if empty else _num(gcm.get_surface_field(v, cols))
-    log.info("Fetching gcm data took %d s" % (time.time() - start))
-    if empty:
+    if not any(cols):                                                        # quirk kept: spcpl.py:63,71
         _current = None
         return None
-    batch = ColumnBatch(get_engine(), les_models, profile_data, surface_data, extra_cols)
-    if _current is not None:   # slab means fetched by get_les_profiles() after the previous step's LES run
+    batch = ColumnBatch(get_engine(), les_models, gcm, cols, extra_cols, couple_surface)
+    log.info("Fetching gcm data took %d s" % (time.time() - start))
+    profile_data, surface_data = batch.gcm_host, batch.surf_host
+    if _current is not None and batch.row is not None:   # slab means fetched by get_les_profiles() after the previous LES run
         batch.profiles = {k: v for k, v in _current.profiles.items() if k in batch.row}
-    for i, les in enumerate(les_models):
-        les._spc_batch = batch
-        if attach_rows:
-            for v in gcm_vars:
-                setattr(les, v, profile_data[v][i][:])
-            for v in surface_data:
-                setattr(les, v, surface_data[v][i])
+    if ens is not None:
+        ens._spc_batch = batch
+    else:
+        for i, les in enumerate(les_models):
+            les._spc_batch = batch
+            if attach_rows:
+                for v in gcm_vars:
+                    setattr(les, v, profile_data[v][i].copy())
+                for v in surface_data:
+                    setattr(les, v, surface_data[v][i])
     # extra output columns: spcpl.py:89-129
     if extra_cols and write and writer is not None:
-        n0 = len(les_models)
+        n0 = batch.n
         C = {var_to_netcdf_name.get(v, v): profile_data[v][n0:] for v in gcm_vars}
         for v in surface_data:
             C[v] = surface_data[v][n0:]
@@ -211,6 +359,8 @@ def gather_gcm_data(gcm, les_models, couple_surface, output_column_indices=None,
 # forward: convert_profiles + set_les_forcings
 # ---------------------------------------------------------------------------------------------
 _FWD_KEYS = ("U", "V", "THL", "QT", "QL", "PS", "Rain")
+_FWD_CORE = ("f_u", "f_v", "f_thl", "f_qt", "f_ql", "ql_ref", "f_ps", "idx")
+_FWD_SURF = ("z0m", "z0h", "wthl", "wqt")
 
 
 def _first_step_profile(les):
@@ -220,17 +370,63 @@ def _first_step_profile(les):
             "Rain": les.get_rain()}
 
 
-def forward_batched(batch, profiles, dt_gcm, factor, couple_surface=False, want_profiles=True):
-    """K1 (+fused K2) for every column of ``batch``. ``profiles``: dict of device tensors U,V,THL,QT,QL
-    [n x nL], PS [n] (+Rain, rain_last [n]). Returns dict of HOST arrays (one D2H per output)."""
-    eng = batch.engine
+def _plan(batch, kind, flags, make):
+    """launch plan of this batch geometry, built once and reused every step (the tensors it binds are views into
+    the StepBuffers, which persist); the test-only oracle engine has no plans and is called directly"""
+    key = (kind,) + tuple(flags)
+    plan = batch.buf.plans.get(key)
+    if plan is None:
+        plan = batch.buf.plans[key] = make()
+    return plan
+
+
+def forward_batched(batch, profiles, dt_gcm, factor, couple_surface=False):
+    """K1 (+fused K2) for every column of ``batch`` -- the LEAN hot-path kernel bench.py times (the six setter
+    arrays, f_ps and the index map; with ``couple_surface`` also the surface fluxes).  ``profiles``: dict of device
+    tensors U,V,THL,QT,QL [n x nL], PS [n] (views of the step's upload buffer).  Returns dict of HOST arrays: views
+    into the pinned download buffer, filled by ONE device->host copy."""
+    eng, b = batch.engine, batch.buf
     dt = float(_num(dt_gcm))
-    res = eng.forward(batch.gcm, batch.zf, profiles, float(factor), dt, zh=batch.zh, want_profiles=want_profiles,
-                      want_heights=True, couple_surface=couple_surface)
-    batch.dev_fwd = res
-    host = {k: v.cpu().numpy() for k, v in res.items()}     # .cpu() synchronises with the launch stream
-    if "ql_ref" in host:
-        host["ql"] = host["ql_ref"]
+    keys = _FWD_CORE + (_FWD_SURF if couple_surface else ())
+    # the surface outputs live behind idx in the buffer; z0m / z0h are pass-throughs written by the kernel too
+    out = {k: b.fwd_out.d[k] for k in _FWD_CORE}
+    prof = {k: profiles[k] for k in ("U", "V", "THL", "QT", "QL", "PS")}
+    if couple_surface:
+        out.update(wthl=b.fwd_out.d["wthl"], wqt=b.fwd_out.d["wqt"])
+    if hasattr(eng, "plan_forward"):
+        plan = _plan(batch, "fwd", (bool(couple_surface),), lambda: eng.plan_forward(
+            batch.gcm, batch.zf, prof, float(factor), dt, zh=batch.zh, want_profiles=False, want_heights=False,
+            couple_surface=couple_surface, out=out))
+        plan.args.factor, plan.args.dt = float(factor), dt
+        plan.launch()
+        res = plan.outputs
+    else:
+        res = eng.forward(batch.gcm, batch.zf, prof, float(factor), dt, zh=batch.zh, want_profiles=False,
+                          want_heights=False, couple_surface=couple_surface, out=out)
+    b.fwd_out.download(upto="wqt" if couple_surface else "idx")
+    host = {k: b.fwd_out.hn[k] for k in _FWD_CORE}
+    if couple_surface:
+        host["wthl"], host["wqt"] = b.fwd_out.hn["wthl"], b.fwd_out.hn["wqt"]
+        host["z0m"] = res["z0m"].cpu().numpy() if "z0m" in res else batch.surf_host["Z0M"][:batch.n]
+        host["z0h"] = res["z0h"].cpu().numpy() if "z0h" in res else batch.surf_host["Z0H"][:batch.n]
+    host["ql"] = host["ql_ref"]
+    return host
+
+
+def _heights(batch):
+    """Zf, Zh (+ Tv, THL, QT) of every column on the host: K5 on the batch, fetched only when somebody needs
+    them (les.gcm_Zf / gcm_Zh of the per-LES API, the spifs writer); spcpl.py:176, 197-198, 214-215."""
+    if getattr(batch, "diag_host", None) is None:
+        batch.diag_host = {k: v.cpu().numpy() for k, v in batch.engine.diagnostics(batch.gcm).items()}
+    return batch.diag_host
+
+
+def _finish_forward(batch, host, rain, rain_last, dt_gcm):
+    dt = float(_num(dt_gcm))
+    host["rain"] = numpy.array(rain, dtype=numpy.float64)
+    host["rainrate"] = (host["rain"] - rain_last) / dt                        # spcpl.py:325 (IEEE: same on host)
+    batch.fwd = host
+    batch.fwd_written = False
     return host
 
 
@@ -251,11 +447,9 @@ def _ensure_forward(batch, les, firststep, profile, dt_gcm, factor, couple_surfa
         src = lambda m: batch.profiles[id(m)]               # noqa: E731
     prof = batch.stack_profiles(_FWD_KEYS, src)
     rain_last = numpy.array([float(_num(getattr(m, "rain", 0.0))) for m in batch.les_models])   # spcpl.py:316-319
-    prof["rain_last"] = torch.from_numpy(rain_last).to(batch.engine.device, batch.engine.dtype)
-    batch.fwd = forward_batched(batch, prof, dt_gcm, factor, couple_surface)
-    batch.fwd["rain"] = prof["Rain"].cpu().numpy()
+    host = forward_batched(batch, prof, dt_gcm, factor, couple_surface)
+    _finish_forward(batch, host, batch.buf.les_in.hn["Rain"], rain_last, dt_gcm)
     batch.fwd_key = key
-    batch.fwd_written = False
     return batch.fwd
 
 
@@ -263,9 +457,9 @@ def _write_forward(batch):
     """spifs rows of convert_profiles + set_les_forcings for ALL columns (spcpl.py:230-244, 352-376)."""
     f, g = batch.fwd, batch.gcm_host
     n = batch.n
-    d = {k: v.cpu().numpy() for k, v in batch.engine.diagnostics(batch.gcm).items()}     # K5: Tv, THL, QT
+    d = _heights(batch)                                                                      # K5: Tv, THL, QT, Zf, Zh
     writer.write(U=g["U"][:n], V=g["V"][:n], T=g["T"][:n], SH=g["SH"][:n], QL=g["QL"][:n], QI=g["QI"][:n],
-                 Pf=g["Pfull"][:n], Ph=g["Phalf"][:n, 1:], Zf=f["Zf"], Zh=f["Zh"][:, 1:], Psurf=g["Phalf"][:n, -1],
+                 Pf=g["Pfull"][:n], Ph=g["Phalf"][:n, 1:], Zf=d["Zf"], Zh=d["Zh"][:, 1:], Psurf=g["Phalf"][:n, -1],
                  Tv=d["Tv"], THL=d["THL"], QT=d["QT"], f_u=f["f_u"], f_v=f["f_v"], f_thl=f["f_thl"], f_qt=f["f_qt"],
                  rain=f["rain"], rainrate=f["rainrate"] * 3600)                              # spcpl.py:358
     if "wthl" in f:
@@ -297,23 +491,23 @@ def set_les_forcings(les, gcm, asynchronous, firststep, profile, dt_gcm, factor,
                      write=True, variability_nudge_constant_T=False):
     """splib/spcpl.py:299-385. The first call of a step computes the forcings of ALL columns in one
     launch; this call then pushes column ``les``'s rows to its setters and returns the request dict."""
-    if qt_forcing == 'variance':
-        raise NotImplementedError("variability_nudge (splib/spcpl.py:613-744) is outside the hot path (SURVEY 8(f4))")
     batch = _batch_of(les)
     f = _ensure_forward(batch, les, firststep, profile, dt_gcm, factor, couple_surface)
     i = batch.index_of(les)
-    les.gcm_Zf, les.gcm_Zh = _wrap("Zf", f["Zf"][i]), _wrap("Zh", f["Zh"][i])   # spcpl.py:200-201
+    d = _heights(batch)
+    les.gcm_Zf, les.gcm_Zh = _wrap("Zf", d["Zf"][i]), _wrap("Zh", d["Zh"][i])   # spcpl.py:200-201
     les.rain = f["rain"][i]                                                  # spcpl.py:324
+    row = lambda k: f[k][i].copy()              # noqa: E731  (f[...] are views of a buffer the next step overwrites)
     req = {
-        "U": les.set_tendency_U(_wrap("f_u", f["f_u"][i]), return_request=asynchronous),                 # :341
-        "V": les.set_tendency_V(_wrap("f_v", f["f_v"][i]), return_request=asynchronous),                 # :342
-        "THL": les.set_tendency_THL(_wrap("f_thl", f["f_thl"][i]), return_request=asynchronous),         # :343
-        "QT": les.set_tendency_QT(_wrap("f_qt", f["f_qt"][i]), return_request=asynchronous),             # :344
+        "U": les.set_tendency_U(_wrap("f_u", row("f_u")), return_request=asynchronous),                 # :341
+        "V": les.set_tendency_V(_wrap("f_v", row("f_v")), return_request=asynchronous),                 # :342
+        "THL": les.set_tendency_THL(_wrap("f_thl", row("f_thl")), return_request=asynchronous),         # :343
+        "QT": les.set_tendency_QT(_wrap("f_qt", row("f_qt")), return_request=asynchronous),             # :344
         "SP": les.set_tendency_surface_pressure(_wrap("f_ps", f["f_ps"][i]), return_request=asynchronous),  # :345
-        "QL": les.set_tendency_QL(_wrap("f_ql", f["f_ql"][i]), return_request=asynchronous),             # :346
-        "QLp": les.set_ref_profile_QL(_wrap("ql_ref", f["ql_ref"][i]), return_request=asynchronous),     # :347
+        "QL": les.set_tendency_QL(_wrap("f_ql", row("f_ql")), return_request=asynchronous),             # :346
+        "QLp": les.set_ref_profile_QL(_wrap("ql_ref", row("ql_ref")), return_request=asynchronous),     # :347
     }
-    les.ql_ref = _wrap("ql_ref", f["ql_ref"][i])                             # spcpl.py:348
+    les.ql_ref = _wrap("ql_ref", row("ql_ref"))                              # spcpl.py:348
     if write and writer is not None and not batch.fwd_written:
         _write_forward(batch)                    # once per launch, for all columns
     if couple_surface:                                                       # spcpl.py:359-364
@@ -321,21 +515,59 @@ def set_les_forcings(les, gcm, asynchronous, firststep, profile, dt_gcm, factor,
         req["Z0H_surf"] = les.set_z0h_surf(_wrap("z0h", f["z0h"][i]), return_request=asynchronous)
         req["WT_surf"] = les.set_wt_surf(_wrap("wthl", f["wthl"][i]), return_request=asynchronous)
         req["WQ_surf"] = les.set_wq_surf(_wrap("wqt", f["wqt"][i]), return_request=asynchronous)
+    if qt_forcing == 'variance':                                             # spcpl.py:377-382
+        if float(_num(les.get_model_time())) > 0:
+            variability_nudge(les, dt_gcm, variability_nudge_constant_T, write=write)
     return req
 
 
 def set_les_forcings_batched(les_models, gcm, asynchronous, firststep, profiles, dt_gcm, factor, couple_surface,
-                             qt_forcing='sp', write=True):
+                             qt_forcing='sp', write=True, variability_nudge_constant_T=False):
     """Batched twin: the whole ``for les in les_models`` loop of splib.step (splib/splib.py:317-323).
-    ``profiles``: dict les -> profile dict (ignored on the first step). Returns list of request dicts."""
-    if not les_models:
+    ``profiles``: dict les -> profile dict (ignored on the first step), or -- with an LES ensemble offering the
+    batched protocol -- what ``get_les_profiles_batched`` returned.  Returns the list of request dicts (empty for
+    an ensemble: its setters are synchronous array hand-overs)."""
+    if not len(les_models):
         return []
+    if _is_ensemble(les_models):
+        return _ensemble_forcings(les_models, firststep, profiles, dt_gcm, factor, couple_surface, qt_forcing, write,
+                                  variability_nudge_constant_T)
     batch = _batch_of(les_models[0])
     if not firststep:
         for les in les_models:
             batch.profiles[id(les)] = profiles[les]
     return [set_les_forcings(les, gcm, asynchronous, firststep, None if firststep else profiles[les], dt_gcm, factor,
-                             couple_surface, qt_forcing, write) for les in les_models]
+                             couple_surface, qt_forcing, write, variability_nudge_constant_T) for les in les_models]
+
+
+def _ensemble_forcings(ens, firststep, profiles, dt_gcm, factor, couple_surface, qt_forcing, write, constant_T):
+    """ONE getter round (first step only), ONE upload, ONE launch, ONE download, ONE setter call per variable for
+    all columns: the fast form of splib.py:317-323 when the LES side offers the batched protocol."""
+    batch = _batch_of(ens)
+    b = batch.buf
+    hn = b.les_in.hn
+    if firststep:                                                            # spcpl.py:302-308, 321
+        ens.get_profiles_batched(_FWD_KEYS, {k: hn[k] for k in _FWD_KEYS})
+        b.les_in.upload()
+        b.rain_prev = numpy.zeros(batch.n)                                   # `except: rain_last = 0`, spcpl.py:316-319
+    elif profiles is None or profiles.get("_buffers") is not b:
+        raise RuntimeError("set_les_forcings_batched: pass what get_les_profiles_batched() returned after the last "
+                           "LES step (the slab means of this batch geometry are not on the device)")
+    dev = b.les_in.d
+    host = forward_batched(batch, dev, dt_gcm, factor, couple_surface)
+    _finish_forward(batch, host, hn["Rain"], getattr(b, "rain_prev", numpy.zeros(batch.n)), dt_gcm)
+    b.rain_prev = host["rain"]                                               # les.rain = rain, spcpl.py:324
+    batch.ql_ref_host = host["ql_ref"]
+    kw = dict(U=host["f_u"], V=host["f_v"], THL=host["f_thl"], QT=host["f_qt"], SP=host["f_ps"], QL=host["f_ql"],
+              QLp=host["ql_ref"])                                            # spcpl.py:341-347
+    if couple_surface:                                                       # spcpl.py:359-364
+        kw.update(Z0M_surf=host["z0m"], Z0H_surf=host["z0h"], WT_surf=host["wthl"], WQ_surf=host["wqt"])
+    ens.set_forcings_batched(**kw)
+    if write and writer is not None:
+        _write_forward(batch)
+    if qt_forcing == 'variance' and float(_num(ens.model_time)) > 0:         # spcpl.py:377-382
+        variability_nudge_batched(ens, dt_gcm, constant_T, write=write)
+    return []
 
 
 def convert_surface_fluxes(les):
@@ -377,18 +609,22 @@ def set_les_state(les, u, v, thl, qt, ps=None):
 # ---------------------------------------------------------------------------------------------
 # LES profiles and the cloud-fraction index map
 # ---------------------------------------------------------------------------------------------
+def _index_map(batch):
+    """[n x nG] int32 host array: searchsorted(zh, Zh, side='right')[:-1][::-1] per column (spcpl.py:26 / 764):
+    the fused K2 output of this step's forward launch, or the standalone K2 before any forward ran"""
+    if batch.fwd is not None and "idx" in batch.fwd:
+        return batch.fwd["idx"]
+    if getattr(batch, "idx_host", None) is None:
+        d = _heights(batch)
+        Zh = torch.from_numpy(d["Zh"]).to(batch.engine.device, batch.engine.dtype)
+        batch.idx_host = batch.engine.cloud_indices(batch.zh, Zh).cpu().numpy()
+    return batch.idx_host
+
+
 def cloud_fraction_indices(les):
     """indices = searchsorted(zh, Zh, side='right')[:-1][::-1]  (splib/spcpl.py:26 / 764), from K2"""
     batch = _batch_of(les)
-    i = batch.index_of(les)
-    if batch.fwd is not None and "idx" in batch.fwd:
-        return batch.fwd["idx"][i]
-    if getattr(batch, "idx_host", None) is None:
-        if getattr(batch, "conv", None) is None:
-            convert_profiles(les, write=False)
-        Zh = torch.from_numpy(batch.conv["Zh"]).to(batch.engine.device, batch.engine.dtype)
-        batch.idx_host = batch.engine.cloud_indices(batch.zh, Zh).cpu().numpy()
-    return batch.idx_host[i]
+    return _index_map(batch)[batch.index_of(les)].copy()
 
 
 def get_cloud_fraction(les):
@@ -419,20 +655,53 @@ def get_les_profiles(les, asynchronous):
     return prof
 
 
+def get_les_profiles_batched(les_models, asynchronous=False, diagnostics=False):
+    """The 14 getters of spcpl.py:747-767 for ALL columns.  With an LES ensemble (batched protocol): one call per
+    group, written straight into the pinned upload buffer, and ONE host->device copy that serves both this
+    step's K3 and the next step's K1; ``diagnostics`` adds presf, Rhof, Rhobf, QR (conservative coarsening / spifs).
+    With a plain list of LES objects: dict les -> get_les_profiles(les)."""
+    if not _is_ensemble(les_models):
+        return {les: get_les_profiles(les, asynchronous) for les in les_models}
+    ens = les_models
+    batch = _batch_of(ens)
+    b = batch.buf
+    hn = b.les_in.hn
+    keys = _LES_IN_LEVELS + ("PS", "Rain") + (_LES_DIAG_LEVELS if diagnostics else ())
+    ens.get_profiles_batched(keys, {k: hn[k] for k in keys})
+    ens.get_cloudfraction_batched(_index_map(batch), hn["A"])                 # spcpl.py:761-765
+    b.les_in.upload()
+    batch.profile_generation += 1
+    prof = {k: hn[k] for k in keys + ("A",)}
+    prof["_buffers"] = b
+    return prof
+
+
 # ---------------------------------------------------------------------------------------------
 # backward: set_gcm_tendencies
 # ---------------------------------------------------------------------------------------------
 _BWD_KEYS = ("T", "QT", "QL", "QL_ice", "U", "V", "A")
+_BWD_OUT = ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A")
 
 
 def backward_batched(batch, profiles, dt_gcm, factor=1, conservative=False):
-    """K3 for every column of ``batch``; ``profiles``: dict of device tensors T,QT,QL,QL_ice,U,V [n x nL],
-    A [n x nG] (+ Rhobf for conservative). Returns dict of HOST arrays."""
-    eng = batch.engine
-    Zf = batch.dev_fwd["Zf"] if getattr(batch, "dev_fwd", None) is not None and "Zf" in batch.dev_fwd else None
-    res = eng.backward(batch.gcm, batch.zf, profiles, float(factor), float(_num(dt_gcm)), Zf=Zf,
-                       conservative=conservative, zh=batch.zh)
-    return {k: v.cpu().numpy() for k, v in res.items()}
+    """K3 (K4 when ``conservative``) for every column of ``batch``; ``profiles``: dict of device tensors
+    T,QT,QL,QL_ice,U,V [n x nL], A [n x nG] (+ Rhobf for conservative).  Zf is recomputed from the geopotential
+    in-kernel (same arithmetic as the forward pass: no height round trip).  Returns dict of HOST arrays, views
+    into the pinned download buffer filled by ONE device->host copy."""
+    eng, b = batch.engine, batch.buf
+    dt = float(_num(dt_gcm))
+    out = {k: b.bwd_out.d[k] for k in _BWD_OUT}
+    out["start_index"] = b.bwd_out.d["start_index"]
+    prof = {k: profiles[k] for k in _BWD_KEYS + (("Rhobf",) if conservative else ())}
+    if hasattr(eng, "plan_backward"):
+        plan = _plan(batch, "bwd", (bool(conservative),), lambda: eng.plan_backward(
+            batch.gcm, batch.zf, prof, float(factor), dt, Zf=None, conservative=conservative, zh=batch.zh, out=out))
+        plan.args.factor, plan.args.dt = float(factor), dt
+        plan.launch()
+    else:
+        eng.backward(batch.gcm, batch.zf, prof, float(factor), dt, Zf=None, conservative=conservative, zh=batch.zh, out=out)
+    b.bwd_out.download()
+    return {k: b.bwd_out.hn[k] for k in _BWD_OUT + ("start_index",)}
 
 
 def set_gcm_tendencies(gcm, les, profile, dt_gcm, factor=1, write=True, conservative=False):
@@ -452,36 +721,49 @@ def set_gcm_tendencies(gcm, les, profile, dt_gcm, factor=1, write=True, conserva
         batch.bwd = backward_batched(batch, prof, dt_gcm, factor, conservative)
         batch.bwd_key = key
         if write and writer is not None:
-            _write_backward(batch, prof)         # once per launch, for all columns
+            extra = batch.stack_profiles(("THL", "presf", "Rhof", "Rhobf", "QR"), lambda m: batch.profiles[id(m)])
+            _write_backward(batch, dict(prof, **extra))      # once per launch, for all columns
     b = batch.bwd
     i = batch.index_of(les)
-    gcm.set_profile_tendency("U", les.grid_index, _wrap("f_U", b["f_U"][i]))     # spcpl.py:535
-    gcm.set_profile_tendency("V", les.grid_index, _wrap("f_V", b["f_V"][i]))
-    gcm.set_profile_tendency("T", les.grid_index, _wrap("f_T", b["f_T"][i]))
-    gcm.set_profile_tendency("SH", les.grid_index, _wrap("f_SH", b["f_SH"][i]))
-    gcm.set_profile_tendency("QL", les.grid_index, _wrap("f_QL", b["f_QL"][i]))
-    gcm.set_profile_tendency("QI", les.grid_index, _wrap("f_QI", b["f_QI"][i]))
-    gcm.set_profile_tendency("A", les.grid_index, _wrap("f_A", b["f_A"][i]))     # spcpl.py:542
+    for var in ("U", "V", "T", "SH", "QL", "QI", "A"):                           # spcpl.py:535-542
+        gcm.set_profile_tendency(var, les.grid_index, _wrap("f_" + var, b["f_" + var][i].copy()))
 
 
 def _write_backward(batch, prof):
-    """spifs rows of set_gcm_tendencies for ALL columns (spcpl.py:412-425, 545-555)."""
+    """spifs rows of set_gcm_tendencies for ALL columns (spcpl.py:412-425, 545-555). ``prof``: device tensors of
+    the slab means incl. THL, presf, Rhof, Rhobf, QR."""
     b, n = batch.bwd, batch.n
-    src = lambda m: batch.profiles[id(m)]        # noqa: E731
-    extra = batch.stack_profiles(("THL", "presf", "Rhof", "Rhobf", "QR"), src)
-    dprof = dict(prof, THL=extra["THL"])
-    d = batch.engine.diagnostics(batch.gcm, batch.zf, dprof)                                 # K5: t, ql_water
+    d = batch.engine.diagnostics(batch.gcm, batch.zf, prof)                                  # K5: t, ql_water
     h = lambda t: t.cpu().numpy()                # noqa: E731
-    writer.write(u=h(prof["U"]), v=h(prof["V"]), presf=h(extra["presf"]), rhof=h(extra["Rhof"]),
-                 rhobf=h(extra["Rhobf"]), qt=h(prof["QT"]), ql=h(prof["QL"]), ql_ice=h(prof["QL_ice"]),
-                 ql_water=h(d["ql_water"]), thl=h(extra["THL"]), t=h(d["t"]), t_=h(prof["T"]), qr=h(extra["QR"]),
+    writer.write(u=h(prof["U"]), v=h(prof["V"]), presf=h(prof["presf"]), rhof=h(prof["Rhof"]),
+                 rhobf=h(prof["Rhobf"]), qt=h(prof["QT"]), ql=h(prof["QL"]), ql_ice=h(prof["QL_ice"]),
+                 ql_water=h(d["ql_water"]), thl=h(prof["THL"]), t=h(d["t"]), t_=h(prof["T"]), qr=h(prof["QR"]),
                  f_U=b["f_U"], f_V=b["f_V"], f_T=b["f_T"], f_SH=b["f_SH"], f_QL=b["f_QL"], f_QI=b["f_QI"], f_A=b["f_A"],
                  A=batch.gcm_host["A"][:n], A_d=h(prof["A"])[:, ::-1])                       # spcpl.py:404,550-551
 
 
 def set_gcm_tendencies_batched(gcm, les_models, profiles, dt_gcm, factor=1, write=True, conservative=False):
-    """Batched twin of the second ``for les`` loop of splib.step (splib/splib.py:330-332)."""
-    if not les_models:
+    """Batched twin of the second ``for les`` loop of splib.step (splib/splib.py:330-332).  With an LES ensemble
+    and a GCM offering ``set_profile_tendencies`` this is ONE launch, ONE download and seven setter calls."""
+    if not len(les_models):
+        return
+    if _is_ensemble(les_models):
+        batch = _batch_of(les_models)
+        b = batch.buf
+        if profiles is None or profiles.get("_buffers") is not b:
+            raise RuntimeError("set_gcm_tendencies_batched: pass what get_les_profiles_batched() returned")
+        if (write and writer is not None or conservative) and "Rhobf" not in profiles:
+            raise RuntimeError("conservative coarsening / spifs output need get_les_profiles_batched(diagnostics=True)")
+        batch.bwd = backward_batched(batch, b.les_in.d, dt_gcm, factor, conservative)
+        if write and writer is not None:
+            _write_backward(batch, b.les_in.d)
+        if hasattr(gcm, "set_profile_tendencies"):
+            for var in ("U", "V", "T", "SH", "QL", "QI", "A"):                   # spcpl.py:535-542
+                gcm.set_profile_tendencies(var, les_models.grid_indices, _wrap("f_" + var, batch.bwd["f_" + var]))
+        else:
+            for i, gi in enumerate(les_models.grid_indices):
+                for var in ("U", "V", "T", "SH", "QL", "QI", "A"):
+                    gcm.set_profile_tendency(var, gi, _wrap("f_" + var, batch.bwd["f_" + var][i].copy()))
         return
     batch = _batch_of(les_models[0])
     for les in les_models:
@@ -498,13 +780,20 @@ def write_les_profiles_batched(les_models):
     splib/splib.py:390): u, v, presf, qt, ql, ql_ice, ql_water, thl, t (from K5 with the GCM pressures,
     spcpl.py:593-594), t_, qr.  One getter round per column (RPC, as in the reference), ONE kernel launch
     and one write per variable for all columns.  Returns the dict of host arrays it wrote."""
-    if not les_models:
+    if not len(les_models):
         return {}
-    batch = _batch_of(les_models[0])
-    src = lambda m: {"U": m.get_profile_U(), "V": m.get_profile_V(), "presf": m.get_presf(),      # noqa: E731
-                     "THL": m.get_profile_THL(), "QT": m.get_profile_QT(), "QL": m.get_profile_QL(),
-                     "QL_ice": m.get_profile_QL_ice(), "QR": m.get_profile_QR(), "T": m.get_profile_T()}
-    prof = batch.stack_profiles(("U", "V", "presf", "THL", "QT", "QL", "QL_ice", "QR", "T"), src)
+    keys = ("U", "V", "presf", "THL", "QT", "QL", "QL_ice", "QR", "T")
+    if _is_ensemble(les_models):
+        batch = _batch_of(les_models)
+        hn = batch.buf.les_in.hn
+        les_models.get_profiles_batched(keys, {k: hn[k] for k in keys})
+        prof = batch.upload_profiles(keys)
+    else:
+        batch = _batch_of(les_models[0])
+        src = lambda m: {"U": m.get_profile_U(), "V": m.get_profile_V(), "presf": m.get_presf(),      # noqa: E731
+                         "THL": m.get_profile_THL(), "QT": m.get_profile_QT(), "QL": m.get_profile_QL(),
+                         "QL_ice": m.get_profile_QL_ice(), "QR": m.get_profile_QR(), "T": m.get_profile_T()}
+        prof = batch.stack_profiles(keys, src)
     d = batch.engine.diagnostics(batch.gcm, batch.zf, prof)                                  # K5: t, ql_water
     h = lambda t: t.cpu().numpy()                # noqa: E731
     out = dict(u=h(prof["U"]), v=h(prof["V"]), presf=h(prof["presf"]), qt=h(prof["QT"]), ql=h(prof["QL"]),
@@ -524,6 +813,17 @@ def write_les_profiles(les):
         batch.wlp_key = key
     i = batch.index_of(les)
     return {k: v[i] for k, v in batch.wlp.items()}
+
+
+# ---------------------------------------------------------------------------------------------
+# variability nudge: splib/spcpl.py:613-744 (qt_forcing == 'variance')
+# ---------------------------------------------------------------------------------------------
+def variability_nudge(les, DT, constantT=False, write=True):
+    raise NotImplementedError("variability_nudge (splib/spcpl.py:613-744): see variability_nudge_batched")
+
+
+def variability_nudge_batched(les_models, DT, constantT=False, write=True):
+    raise NotImplementedError("variability_nudge (splib/spcpl.py:613-744)")
 
 
 # ---------------------------------------------------------------------------------------------

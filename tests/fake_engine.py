@@ -12,14 +12,23 @@ def _np(d):
     return {k: v.numpy() for k, v in d.items()}
 
 
-def _t(d):
-    return {k: torch.from_numpy(numpy.ascontiguousarray(v)) for k, v in d.items()}
+def _t(d, out=None):
+    """results as torch CPU tensors; written INTO the caller's ``out`` tensors where given (the product hands
+    views of its transfer buffers, like it does to the HIP engine's plans)"""
+    res = {}
+    for k, v in d.items():
+        t = torch.from_numpy(numpy.ascontiguousarray(v))
+        if out is not None and k in out:
+            out[k].copy_(t.to(out[k].dtype))
+            t = out[k]
+        res[k] = t
+    return res
 
 
 class OracleEngine:
     device, dtype = torch.device("cpu"), torch.float64
 
-    def forward(self, g, zf, p, factor, dt, zh=None, want_profiles=False, want_heights=True, couple_surface=False, **kw):
+    def forward(self, g, zf, p, factor, dt, zh=None, want_profiles=False, want_heights=True, couple_surface=False, out=None, **kw):
         pn = _np(p)
         r = orc.forward_batched(_np(g), pn, zf.numpy(), None if zh is None else zh.numpy(), factor, dt,
                                 couple_surface=couple_surface)
@@ -34,9 +43,9 @@ class OracleEngine:
             keep += ["rainrate"]
         if couple_surface:
             keep += ["z0m", "z0h", "wthl", "wqt"]
-        return _t({k: r[k] for k in keep})
+        return _t({k: r[k] for k in keep}, out)
 
-    def backward(self, g, zf, p, factor, dt, Zf=None, conservative=False, zh=None, Zh=None, **kw):
+    def backward(self, g, zf, p, factor, dt, Zf=None, conservative=False, zh=None, Zh=None, out=None, **kw):
         gn = _np(g)
         if Zf is None:
             Zf_n = (gn["Zgfull"] - gn["Zghalf"][:, -1:]) / orc.grav
@@ -48,9 +57,9 @@ class OracleEngine:
         pn.setdefault("THL", numpy.zeros_like(pn["T"]))   # only feeds the oracle's `t` diagnostic
         r = orc.backward_batched(gn, Zf_n, pn, zf.numpy(), factor, dt, conservative=conservative, Zh=Zh_n,
                                  zh=None if zh is None else zh.numpy())
-        out = {k: r[k] for k in ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A")}
-        out["start_index"] = r["start_index"].astype(numpy.int32)
-        return _t(out)
+        res = {k: r[k] for k in ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A")}
+        res["start_index"] = r["start_index"].astype(numpy.int32)
+        return _t(res, out)
 
     def cloud_indices(self, zh, Zh, **kw):
         zhn, Zhn = zh.numpy(), Zh.numpy()

@@ -251,3 +251,28 @@ def test_get_cloudfraction_like_the_reference_test():
     tolerance = 1.e-10                                                         # spcpl_test.py:7
     assert abs(A[0] - (0.5 + 0.2 * numpy.cos(6. * (1. - k) / k))) < tolerance    # spcpl_test.py:15
     assert abs(A[-1] - (0.5 + 0.2)) < tolerance                                # spcpl_test.py:16
+
+
+@pytest.mark.parametrize("cplsurf,conservative", [(False, False), (True, False), (False, True)])
+def test_batched_model_protocol_on_the_gpu_equals_the_per_les_path(cplsurf, conservative):
+    """The fast drop-in transport (LES ensemble + batched GCM calls: one pinned upload, one launch, one download per
+    direction) against the reference-style per-LES calls on identical models: the SAME kernels run either way, so
+    the model states must stay bit-identical over a closed loop of several steps."""
+    from sp_coupler_amd import spcpl
+    from sp_coupler_amd.driver import Coupler
+    spcpl.set_engine(None)
+    n_les, nsteps = 37, 3
+    gcm_a, les_a = models.make_models(n_les, nG=91, nL=160, seed=23)
+    gcm_b, les_b = models.make_models(n_les, nG=91, nL=160, seed=23)
+    gcm_b.__class__ = models.BatchedSyntheticGCM
+    ens = models.SyntheticLESEnsemble.from_models(les_b)
+    Coupler(gcm_a, les_a, cplsurf=cplsurf, les_forcing_factor=0.9, gcm_forcing_factor=1.1,
+            conservative_coarsening=conservative).run(nsteps)
+    Coupler(gcm_b, ens, cplsurf=cplsurf, les_forcing_factor=0.9, gcm_forcing_factor=1.1,
+            conservative_coarsening=conservative).run(nsteps)
+    for var in gcm_a.state:
+        assert numpy.array_equal(gcm_a.state[var], gcm_b.state[var]), var
+    for i, m in enumerate(les_a):
+        for k in ("U", "V", "THL", "QT", "QL", "T", "PS", "Rain"):
+            assert numpy.array_equal(numpy.asarray(m.p[k]), ens.p[k][i]), (k, i)
+    assert not numpy.array_equal(gcm_a.state["T"], models.make_models(n_les, nG=91, nL=160, seed=23)[0].state["T"])

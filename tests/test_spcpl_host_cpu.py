@@ -56,8 +56,7 @@ def test_per_les_calls_need_all_profiles_and_stale_profiles_are_not_reused():
         spcpl.set_les_forcings(les_models[0], gcm, True, False, {"U": 0}, dt_gcm=900.0, factor=1.0, couple_surface=False)
     with pytest.raises(RuntimeError, match="gather_gcm_data"):
         spcpl.set_les_forcings(models.SyntheticLES(gcm, 2), gcm, True, True, {}, 900.0, 1.0, False)
-    with pytest.raises(NotImplementedError):
-        spcpl.set_les_forcings(les_models[0], gcm, True, True, {}, 900.0, 1.0, False, qt_forcing="variance")
+
     # first step: live getters, all columns in one (fake) launch, request dict per column
     reqs = spcpl.set_les_forcings_batched(les_models, gcm, True, True, {}, 900.0, 1.0, False)
     assert len(reqs) == 3 and all(set(r) == {"U", "V", "THL", "QT", "SP", "QL", "QLp"} for r in reqs)
@@ -182,3 +181,45 @@ def test_full_steps_with_extra_output_columns_and_a_writer(tmp_path):
     assert numpy.isfinite(sp["f_T"]).all() and numpy.isfinite(sp["f_u"]).all() and numpy.isfinite(sp["Tv"]).all()
     assert numpy.isfinite(ex["Tv"]).all() and numpy.isfinite(ex["wthl"]).all()      # extra column kept its rows
     assert numpy.isnan(ex["f_T"]).all()                                              # and received no SP tendencies
+
+
+@pytest.mark.parametrize("cplsurf,conservative,write", [(False, False, False), (True, False, True), (False, True, False)])
+def test_batched_model_protocol_equals_the_per_les_path(tmp_path, cplsurf, conservative, write):
+    """The optional batched protocol (LES ensemble + GCM out=/set_profile_tendencies; models.py, INTEGRATION.md
+    section 4) must drive the models to EXACTLY the state the reference-style per-LES calls produce: same kernels,
+    same arithmetic, only the transport differs (one call per variable instead of ~20 per column)."""
+    from sp_coupler_amd import spio
+    from sp_coupler_amd.driver import Coupler
+    n_les, nsteps = 6, 3
+    gcm_a, les_a = models.make_models(n_les, nG=19, nL=160, seed=9)
+    gcm_b, les_b = models.make_models(n_les, nG=19, nL=160, seed=9)
+    gcm_b.__class__ = models.BatchedSyntheticGCM                       # same state, batched protocol switched on
+    ens = models.SyntheticLESEnsemble.from_models(les_b)
+    files = []
+    for tag, gcm, les in (("a", gcm_a, les_a), ("b", gcm_b, ens)):
+        if write:
+            path = str(tmp_path / ("spifs_%s.nc" % tag))
+            idx = [m.grid_index for m in les_a]
+            spcpl.writer = spio.SpifsWriter(path, idx, [0] * n_les, [0] * n_les, les_a[0].zf_cache, 19)
+            files.append(path)
+        cpl = Coupler(gcm, les, cplsurf=cplsurf, les_forcing_factor=0.7, gcm_forcing_factor=1.3,
+                      conservative_coarsening=conservative, write=write)
+        cpl.run(nsteps)
+        assert not cpl.firststep and len(cpl.timing_rows) == nsteps
+        if write:
+            spcpl.writer.close()
+            spcpl.writer = None
+    for var in gcm_a.state:
+        assert numpy.array_equal(gcm_a.state[var], gcm_b.state[var]), var
+    for i, m in enumerate(les_a):
+        for k in ("U", "V", "THL", "QT", "QL", "T", "PS", "Rain"):
+            assert numpy.array_equal(numpy.asarray(m.p[k]), ens.p[k][i]), (k, i)
+    assert ens.model_time == les_a[0].model_time == 2700.0
+    if write:
+        ca, cb = spio.read_column(files[0], 4), spio.read_column(files[1], 4)
+        assert set(ca) == set(cb)
+        for k in ca:
+            assert numpy.array_equal(ca[k], cb[k], equal_nan=True), k
+        assert numpy.isfinite(cb["f_T"]).all() and numpy.isfinite(cb["rainrate"]).all()
+    # the per-column faces of an ensemble speak the reference's per-LES protocol too
+    assert ens[2].get_profile_U().shape == (160,) and ens[2].grid_index == les_a[2].grid_index

@@ -17,6 +17,7 @@
  *   spc_backward_*       <- spcpl.set_gcm_tendencies      splib/spcpl.py:388-555 (arithmetic 402-533)
  *                           sputils.interp_c / integral   splib/sputils.py:94-189 (conservative=1)
  *   spc_surface_fluxes_* <- spcpl.convert_surface_fluxes  splib/spcpl.py:136-167 (columns without LES)
+ *   spc_variability_nudge_f64 <- spcpl.variability_nudge  splib/spcpl.py:613-744 (qt_forcing == 'variance')
  *   spc_diagnostics_*    <- spifs.nc diagnostics          splib/spcpl.py:176,214-215,408-409;
  *                           spcpl.output_column_conversion splib/spcpl.py:251-267
  *
@@ -157,6 +158,32 @@ int spc_surface_fluxes_f64(int64_t n, const void *Ph_s, const void *T_s, const v
                            const void *SHflux, const void *TSflux, void *wthl, void *wqt, void *stream);
 int spc_surface_fluxes_f32(int64_t n, const void *Ph_s, const void *T_s, const void *QLflux, const void *QIflux,
                            const void *SHflux, const void *TSflux, void *wthl, void *wqt, void *stream);
+
+/* ---- variability nudge (qt_forcing == 'variance'): spcpl.variability_nudge, splib/spcpl.py:613-744 ------------ */
+/* 3-D LES fields in the reference's layout [n_cols][itot][jtot][ktot] (k fastest), float64.  For every level the
+ * kernel finds beta (multiplicative, brentq on [0,5]) or a (additive noise a*R, brentq on [0,5]) such that the plane
+ * mean of max(qt' - qsat, 0) equals ql_ref[k], updates qt in place (and thl with constantT), and returns beta, a,
+ * qt.std(axis=(0,1)) and a status word per (column, level):
+ *   bit 0 multiplicative root found, 1 "barely unsaturated" branch (spcpl.py:679-695), 2 additive root found,
+ *   3 additive branch skipped (ql_ref <= ql_av), 4 no bracket -> beta_max; bit 8: brentq sign error (the reference
+ *   raises ValueError there), bit 9: no convergence in 100 iterations (RuntimeError).
+ * R: [n_cols][itot*jtot] the zero-mean Gaussian field of spcpl.py:620-621, drawn by the caller.                    */
+typedef struct spc_vnudge_args {
+    int64_t n_cols;
+    int32_t itot, jtot, ktot;
+    int32_t constantT;                 /* variability_nudge_constant_T */
+    void *qt;                          /* [n][itot][jtot][ktot] in/out: les.get_field("QT") -> les.fields.QT  */
+    const void *qsat;                  /* [n][itot][jtot][ktot] les.get_field("Qsat")                         */
+    void *thl;                         /* in/out, constantT only: les.get_field("THL")                        */
+    const void *ql;                    /* constantT only: les.get_field("QL")                                 */
+    const void *R;                     /* [n][itot*jtot]                                                      */
+    const void *ql_av, *qt_av, *presf; /* [n][ktot] les.get_profile("QL"/"QT"), les.get_presf()               */
+    const void *ql_ref;                /* [n][ktot] les.ql_ref (K1's ql_ref output)                           */
+    void *beta, *a_add, *qt_std;       /* [n][ktot] outputs                                                   */
+    int32_t *status;                   /* [n][ktot] output                                                    */
+} spc_vnudge_args;
+
+int spc_variability_nudge_f64(const spc_vnudge_args *args, void *stream);
 
 /* ---- misc ----------------------------------------------------------------------------------- */
 int spc_abi_version(void);          /* == SPC_ABI_VERSION                                          */

@@ -64,6 +64,11 @@ class DiagnosticsArgs(ctypes.Structure):
                      "Tv", "THL", "QT", "Zf", "Zh", "pf", "t", "ql_water")
 
 
+class VnudgeArgs(ctypes.Structure):
+    _fields_ = ([("n_cols", c_int64), ("itot", c_int32), ("jtot", c_int32), ("ktot", c_int32), ("constantT", c_int32)]
+                + _ptrs("qt", "qsat", "thl", "ql", "R", "ql_av", "qt_av", "presf", "ql_ref", "beta", "a_add", "qt_std", "status"))
+
+
 #: every symbol include/spc.h declares: name -> (restype, argtypes)
 PROTOTYPES = {
     "spc_forward_f64": (ctypes.c_int, [ctypes.POINTER(Dims), ctypes.POINTER(ForwardArgs), c_void_p]),
@@ -76,6 +81,7 @@ PROTOTYPES = {
     "spc_diagnostics_f32": (ctypes.c_int, [ctypes.POINTER(Dims), ctypes.POINTER(DiagnosticsArgs), c_void_p]),
     "spc_surface_fluxes_f64": (ctypes.c_int, [c_int64] + [c_void_p] * 9),
     "spc_surface_fluxes_f32": (ctypes.c_int, [c_int64] + [c_void_p] * 9),
+    "spc_variability_nudge_f64": (ctypes.c_int, [ctypes.POINTER(VnudgeArgs), c_void_p]),
     "spc_abi_version": (ctypes.c_int, []),
     "spc_last_error": (ctypes.c_char_p, []),
     "spc_device_count": (ctypes.c_int, []),

@@ -685,6 +685,8 @@ template <typename T, int NG, int NL, int WT> __global__ __launch_bounds__(BLOCK
 
 #include "spc_v2.hpp"
 
+#include "spc_vnudge.hpp"
+
 // =================================================================================================
 // K4 backward, conservative coarsening: splib/spcpl.py:479-489 -> sputils.interp_c / integral
 // (splib/sputils.py:94-189).  Same tendencies / masking as K3, but each GCM level receives the
@@ -1407,6 +1409,27 @@ int spc_surface_fluxes_f32(int64_t n, const void *Ph_s, const void *T_s, const v
                            const void *SHflux, const void *TSflux, void *wthl, void *wqt, void *stream)
 {
     return surface_impl<float>(n, Ph_s, T_s, QLflux, QIflux, SHflux, TSflux, wthl, wqt, stream);
+}
+
+int spc_variability_nudge_f64(const spc_vnudge_args *a, void *stream)
+{
+    if (!a) return fail(SPC_ERR_INVALID_ARGUMENT, "%sargs is NULL");
+    if (a->n_cols < 0 || a->itot < 1 || a->jtot < 1 || a->ktot < 1 || (int64_t)a->itot * a->jtot > INT32_MAX / 2)
+        return fail(SPC_ERR_INVALID_ARGUMENT, "%svariability_nudge: bad extents");
+    if (a->n_cols == 0) return SPC_OK;
+    REQUIRE(a->qt, "qt"); REQUIRE(a->qsat, "qsat"); REQUIRE(a->R, "R"); REQUIRE(a->ql_av, "ql_av"); REQUIRE(a->qt_av, "qt_av");
+    REQUIRE(a->ql_ref, "ql_ref"); REQUIRE(a->beta, "beta"); REQUIRE(a->a_add, "a_add"); REQUIRE(a->qt_std, "qt_std");
+    REQUIRE(a->status, "status");
+    if (a->constantT) { REQUIRE(a->thl, "thl (constantT)"); REQUIRE(a->ql, "ql (constantT)"); REQUIRE(a->presf, "presf (constantT)"); }
+    if (a->n_cols > 65535) return fail(SPC_ERR_UNSUPPORTED, "%svariability_nudge: more than 65535 columns per launch");
+    VnP p;
+    p.n_cols = a->n_cols; p.nij = a->itot * a->jtot; p.ktot = a->ktot; p.constantT = a->constantT; p.pad = 0;
+    p.qsat = (const double *)a->qsat; p.R = (const double *)a->R; p.ql_av = (const double *)a->ql_av; p.qt_av = (const double *)a->qt_av;
+    p.presf = (const double *)a->presf; p.ql_ref = (const double *)a->ql_ref; p.ql = (const double *)a->ql;
+    p.qt = (double *)a->qt; p.thl = (double *)a->thl; p.beta = (double *)a->beta; p.a_add = (double *)a->a_add;
+    p.qt_std = (double *)a->qt_std; p.status = a->status;
+    hipLaunchKernelGGL(k_vnudge, dim3((unsigned)((a->ktot + 63) / 64), (unsigned)a->n_cols), dim3(64), 0, (hipStream_t)stream, p);
+    return launch_status("k_vnudge");
 }
 
 int spc_abi_version(void) { return SPC_ABI_VERSION; }

@@ -341,6 +341,43 @@ class Engine:
         _abi.check(self.lib, rc)
         return res
 
+    # -- variability nudge (qt_forcing == 'variance') ------------------------------------------------
+    def variability_nudge(self, qt, qsat, R, ql_av, qt_av, ql_ref, presf=None, thl=None, ql=None, constantT=False,
+                          stream=None):
+        """spcpl.variability_nudge (splib/spcpl.py:613-744) for all columns: ``qt`` [n x itot x jtot x k] is updated
+        IN PLACE (``thl`` too with ``constantT``); returns dict beta, a, qt_std [n x k] and status [n x k] int32."""
+        if self.dtype != torch.float64:
+            raise ValueError("variability_nudge computes in float64 only (bit parity with numpy / scipy)")
+        if qt.dim() != 4:
+            raise ValueError("qt must be [n x itot x jtot x ktot]")
+        n, itot, jtot, ktot = (int(x) for x in qt.shape)
+        ck = _Checker(self.device, self.dtype)
+
+        def field(name, t):
+            if not isinstance(t, torch.Tensor) or t.device != self.device or t.dtype != self.dtype or \
+                    tuple(t.shape) != (n, itot, jtot, ktot) or not t.is_contiguous():
+                raise ValueError("%s must be a contiguous float64 [%d x %d x %d x %d] tensor on %s" % (name, n, itot, jtot, ktot, self.device))
+            ck.keep.append(t)
+            return t.data_ptr()
+        a = _abi.VnudgeArgs()
+        a.n_cols, a.itot, a.jtot, a.ktot, a.constantT = n, itot, jtot, ktot, 1 if constantT else 0
+        a.qt, a.qsat = field("qt", qt), field("qsat", qsat)
+        a.R, _ = ck.mat("R", R.reshape(n, itot * jtot), n, itot * jtot)
+        for name, t in (("ql_av", ql_av), ("qt_av", qt_av), ("ql_ref", ql_ref)):
+            ptr, _ = ck.mat(name, t, n, ktot, ktot)
+            setattr(a, name, ptr)
+        if constantT:
+            a.thl, a.ql = field("thl", thl), field("ql", ql)
+            a.presf, _ = ck.mat("presf", presf, n, ktot, ktot)
+        res = {k: self.empty(n, ktot) for k in ("beta", "a", "qt_std")}
+        res["status"] = self.empty(n, ktot, dtype=torch.int32)
+        a.beta, a.a_add, a.qt_std, a.status = (res["beta"].data_ptr(), res["a"].data_ptr(), res["qt_std"].data_ptr(),
+                                               res["status"].data_ptr())
+        with torch.cuda.device(self.device):
+            rc = self.lib.spc_variability_nudge_f64(ctypes.byref(a), _stream_ptr(stream, self.device))
+        _abi.check(self.lib, rc)
+        return res
+
     # -- surface fluxes of columns without an LES -------------------------------------------------
     def surface_fluxes(self, Ph_s, T_s, QLflux, QIflux, SHflux, TSflux, stream=None):
         """(wthl, wqt) of spcpl.convert_surface_fluxes (splib/spcpl.py:153-161) for [n] scalars."""

@@ -402,7 +402,10 @@ def _row_getter(key):
 def _row_setter(name):
     def set_(self, values, return_request=False):
         v = numpy.asarray(getattr(values, "number", values), dtype=numpy.float64)
-        self._e.tend.setdefault(name, self._e._zeros_like_tend(name))[self._i] = v
+        t = self._e.tend.get(name)
+        if t is None:
+            t = self._e.tend[name] = self._e._zeros_like_tend(name)
+        t[self._i] = v
         self.received.append(name)
         return _ret(None, return_request)
     return set_

@@ -536,8 +536,13 @@ def set_les_forcings_batched(les_models, gcm, asynchronous, firststep, profiles,
     if not firststep:
         for les in les_models:
             batch.profiles[id(les)] = profiles[les]
-    return [set_les_forcings(les, gcm, asynchronous, firststep, None if firststep else profiles[les], dt_gcm, factor,
-                             couple_surface, qt_forcing, write, variability_nudge_constant_T) for les in les_models]
+    reqs = [set_les_forcings(les, gcm, asynchronous, firststep, None if firststep else profiles[les], dt_gcm, factor,
+                             couple_surface, 'sp', write) for les in les_models]
+    if qt_forcing == 'variance':       # spcpl.py:377-382, for all LES in one launch (R drawn in the same les order)
+        started = [les for les in les_models if float(_num(les.get_model_time())) > 0]
+        if started:
+            variability_nudge_batched(started, dt_gcm, variability_nudge_constant_T, write=write)
+    return reqs
 
 
 def _ensemble_forcings(ens, firststep, profiles, dt_gcm, factor, couple_surface, qt_forcing, write, constant_T):
@@ -566,7 +571,7 @@ def _ensemble_forcings(ens, firststep, profiles, dt_gcm, factor, couple_surface,
     if write and writer is not None:
         _write_forward(batch)
     if qt_forcing == 'variance' and float(_num(ens.model_time)) > 0:         # spcpl.py:377-382
-        variability_nudge_batched(ens, dt_gcm, constant_T, write=write)
+        variability_nudge_batched(list(ens), dt_gcm, constant_T, write=write)
     return []
 
 
@@ -624,7 +629,11 @@ def _index_map(batch):
 def cloud_fraction_indices(les):
     """indices = searchsorted(zh, Zh, side='right')[:-1][::-1]  (splib/spcpl.py:26 / 764), from K2"""
     batch = _batch_of(les)
-    return _index_map(batch)[batch.index_of(les)].copy()
+    i = batch.index_of(les)
+    if batch.fwd is None:        # before any forward launch of this step: heights as convert_profiles caches them
+        d = _heights(batch)
+        les.gcm_Zf, les.gcm_Zh = _wrap("Zf", d["Zf"][i]), _wrap("Zh", d["Zh"][i])       # spcpl.py:200-201
+    return _index_map(batch)[i].copy()
 
 
 def get_cloud_fraction(les):
@@ -818,12 +827,76 @@ def write_les_profiles(les):
 # ---------------------------------------------------------------------------------------------
 # variability nudge: splib/spcpl.py:613-744 (qt_forcing == 'variance')
 # ---------------------------------------------------------------------------------------------
+VN_ERR_SIGN, VN_ERR_CONV = 256, 512          # status bits of spc_variability_nudge_f64 (include/spc.h)
+
+
 def variability_nudge(les, DT, constantT=False, write=True):
-    raise NotImplementedError("variability_nudge (splib/spcpl.py:613-744): see variability_nudge_batched")
+    """splib/spcpl.py:613-744 for one LES (the reference's signature): see variability_nudge_batched."""
+    return variability_nudge_batched([les], DT, constantT, write)[0]
 
 
 def variability_nudge_batched(les_models, DT, constantT=False, write=True):
-    raise NotImplementedError("variability_nudge (splib/spcpl.py:613-744)")
+    """spcpl.variability_nudge (splib/spcpl.py:613-744) for every LES in ONE launch.  Per LES, as the reference:
+    a zero-mean Gaussian field R from numpy's GLOBAL generator (spcpl.py:620-621, drawn in les order), the 3-D
+    fields ``les.get_field("Qsat"/"QT")`` (+ "THL", "QL" with constantT), the slab means ``les.get_profile("QL"/"QT")``,
+    ``les.get_presf()`` and ``les.ql_ref``; afterwards ``les.fields.QT`` (and ``.THL``) are set and qt_alpha, qt_beta,
+    qt_std written to spifs.  Returns a list of dicts (beta, alpha, qt_std, a, status) per LES.  Where scipy's
+    brentq would raise (no sign change for the additive noise / no convergence) this raises the same exception
+    type AFTER the launch; levels that were fine have been applied."""
+    les_models = list(les_models)
+    if not les_models:
+        return []
+    eng = get_engine()
+    dev, dt = eng.device, eng.dtype
+    dtv = float(_num(DT))
+    Rs, F = [], {k: [] for k in ("qsat", "qt", "ql_av", "qt_av", "presf", "ql_ref", "thl", "ql")}
+    for les in les_models:
+        itot, jtot = int(les.get_itot()), int(les.get_jtot())
+        R = numpy.random.normal(size=(itot, jtot))                            # spcpl.py:620
+        R -= R.sum() / (itot * jtot)                                          # spcpl.py:621
+        Rs.append(R)
+        F["qsat"].append(_num(les.get_field("Qsat")))                         # spcpl.py:627-632
+        F["qt"].append(_num(les.get_field("QT")))
+        F["ql_av"].append(_num(les.get_profile("QL")))
+        F["qt_av"].append(_num(les.get_profile("QT")))
+        F["presf"].append(_num(les.get_presf()))
+        F["ql_ref"].append(_num(les.ql_ref))
+        if constantT:                                                         # spcpl.py:634-636
+            F["thl"].append(_num(les.get_field("THL")))
+            F["ql"].append(_num(les.get_field("QL")))
+    up = lambda rows: torch.from_numpy(numpy.ascontiguousarray(numpy.stack(rows))).to(dev, dt)      # noqa: E731
+    T = {k: up(v) for k, v in F.items() if v}
+    res = eng.variability_nudge(T["qt"], T["qsat"], up(Rs), T["ql_av"], T["qt_av"], T["ql_ref"], presf=T["presf"],
+                                thl=T.get("thl"), ql=T.get("ql"), constantT=constantT)
+    host = {k: v.cpu().numpy() for k, v in res.items()}
+    qt_new = T["qt"].cpu().numpy()
+    thl_new = T["thl"].cpu().numpy() if constantT else None
+    out = []
+    for i, les in enumerate(les_models):
+        target = les.fields if hasattr(les, "fields") else None
+        if target is not None:
+            target.QT = _wrap("qt", qt_new[i])                                # spcpl.py:735
+            if constantT:
+                target.THL = _wrap("thl", thl_new[i])                         # spcpl.py:736-737
+        else:
+            les.set_field("QT", _wrap("qt", qt_new[i]))
+            if constantT:
+                les.set_field("THL", _wrap("thl", thl_new[i]))
+        beta = host["beta"][i]
+        alpha = numpy.log(beta) / dtv                                         # spcpl.py:739
+        out.append(dict(beta=beta, alpha=alpha, qt_std=host["qt_std"][i], a=host["a"][i], status=host["status"][i]))
+    if write and writer is not None:                                          # spcpl.py:742-744
+        rows = [_batch_of(les).index_of(les) for les in les_models]
+        writer.write(rows=rows, qt_alpha=numpy.stack([o["alpha"] for o in out]),
+                     qt_beta=numpy.stack([o["beta"] for o in out]), qt_std=numpy.stack([o["qt_std"] for o in out]))
+    st = host["status"]
+    if (st & VN_ERR_SIGN).any():
+        i, k = numpy.argwhere((st & VN_ERR_SIGN) != 0)[0]
+        raise ValueError("f(a) and f(b) must have different signs (variability nudge, LES %d level %d)" % (i, k))
+    if (st & VN_ERR_CONV).any():
+        i, k = numpy.argwhere((st & VN_ERR_CONV) != 0)[0]
+        raise RuntimeError("Failed to converge after 100 iterations. (variability nudge, LES %d level %d)" % (i, k))
+    return out
 
 
 # ---------------------------------------------------------------------------------------------

@@ -17,7 +17,8 @@ from scipy.io import netcdf_file
 # (name, unit) on LES levels -- spio.py:133-152
 LES_LEVEL_VARS = (('u', 'm/s'), ('v', 'm/s'), ('thl', 'K'), ('qt', '1'), ('ql', '1'), ('ql_ice', '1'), ('ql_water', '1'),
                   ('qr', '1'), ('t', 'K'), ('t_', 'K'), ('f_u', 'm/s'), ('f_v', 'm/s'), ('f_thl', 'K/s'), ('f_qt', '1/s'),
-                  ('presf', 'Pa/s'), ('rhof', 'kg/m^3'), ('rhobf', 'kg/m^3'))
+                  ('presf', 'Pa/s'), ('rhof', 'kg/m^3'), ('rhobf', 'kg/m^3'), ('qt_std', '1'), ('qt_alpha', '1/s'),
+                  ('qt_beta', '1'))
 # on GCM levels -- spio.py:158-164 (tendencies) and 176-190 (state)
 GCM_LEVEL_VARS = (('f_U', 'm/s'), ('f_V', 'm/s'), ('f_T', 'K/s'), ('f_SH', '1/s'), ('f_QL', '1/s'), ('f_QI', '1/s'),
                   ('f_A', '1/s'), ('U', 'm/s'), ('V', 'm/s'), ('T', 'K'), ('SH', '1'), ('QL', '1'), ('QI', '1'), ('Pf', 'Pa'),

@@ -43,7 +43,8 @@ def test_struct_layout_matches_c_compiler(tmp_path):
     probes = [("spc_dims", _abi.Dims, ["n_cols", "nG", "nL", "pitchG", "pitchGh", "pitchL", "les_grid_shared", "cols_per_block"]),
               ("spc_forward_args", _abi.ForwardArgs, ["U", "zf", "rain_last", "factor", "dt", "f_u", "idx", "Z0M", "wqt"]),
               ("spc_backward_args", _abi.BackwardArgs, ["T", "A_prof", "rhobf_d", "conservative", "factor", "dt", "f_T", "start_index"]),
-              ("spc_diagnostics_args", _abi.DiagnosticsArgs, ["T", "zf", "Tv", "ql_water"])]
+              ("spc_diagnostics_args", _abi.DiagnosticsArgs, ["T", "zf", "Tv", "ql_water"]),
+              ("spc_vnudge_args", _abi.VnudgeArgs, ["n_cols", "itot", "ktot", "constantT", "qt", "R", "presf", "beta", "status"])]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "spc.h"', 'int main(void){']
     for cname, _, fields in probes:
         lines.append('printf("%%zu\\n", sizeof(%s));' % cname)

@@ -1,0 +1,183 @@
+"""variability nudge (splib/spcpl.py:613-744).  PARITY UNPINNED: the reference's tests hold no
+fixture for it.  CPU part: the oracle (NumPy + scipy.optimize.brentq, as the reference) does what the algorithm
+promises, and the scalar restatements of brentq / ndarray.sum() that the HIP kernel re-implements equal the
+library routines bit for bit.  GPU part (-m gpu): the kernel against the oracle."""
+import math
+
+import numpy
+import pytest
+from scipy.optimize import brentq
+
+from oracle import vnudge_oracle as vo
+
+
+def make_les_fields(itot, jtot, ktot, seed, cloudy=True):
+    """3-D qt / qsat / thl / ql of one synthetic LES plus slab means and a GCM ql_ref with levels in every branch of
+    the algorithm: clouds to match (brentq), too little variability (no bracket -> additive noise), LES cloudier than
+    the GCM (barely-unsaturated branch), clear levels (no nudge)."""
+    rng = numpy.random.default_rng(seed)
+    z = (numpy.arange(ktot) + 0.5) / ktot
+    qsat_prof = 0.016 * numpy.exp(-3.0 * z)
+    qt_prof = qsat_prof * (0.75 + 0.3 * numpy.exp(-((z - 0.35) / 0.15) ** 2))
+    sig = 0.04 * qt_prof * (0.2 + z)
+    qt = qt_prof[None, None, :] + sig[None, None, :] * rng.normal(size=(itot, jtot, ktot))
+    qsat = qsat_prof[None, None, :] * (1 + 0.01 * rng.normal(size=(itot, jtot, ktot)))
+    ql = numpy.maximum(qt - qsat, 0.0)
+    ql_av, qt_av = ql.mean(axis=(0, 1)), qt.mean(axis=(0, 1))
+    presf = 1e5 * numpy.exp(-0.5 * z)
+    thl = 290.0 + 10 * z[None, None, :] + 0.1 * rng.normal(size=(itot, jtot, ktot))
+    ql_ref = ql_av * rng.uniform(0.3, 3.0, ktot)
+    ql_ref[::7] = 0.0                                   # GCM says clear
+    cl = numpy.nonzero(ql_av > 1e-7)[0]
+    ql_ref[cl[1::3]] = 0.0                              # ... also where the LES has cloud: "barely unsaturated" branch
+    ql_ref[3::11] = 5e-4                                # far more cloud than the LES variability can produce
+    if cloudy:
+        ql_ref[5::13] = ql_av[5::13] + 2e-5
+    return dict(qt=qt, qsat=qsat, ql=ql, thl=thl, ql_av=ql_av, qt_av=qt_av, presf=presf, ql_ref=ql_ref)
+
+
+def test_brentq_restatement_equals_scipy_bit_for_bit():
+    rng = numpy.random.default_rng(0)
+    compared = 0
+    for t in range(1500):
+        kind = t % 3
+        if kind == 0:
+            c = rng.uniform(0.1, 4.9)
+            f = lambda x, c=c: (x - c) ** 3 + 0.1 * (x - c)                                        # noqa: E731
+        elif kind == 1:
+            qt = rng.normal(8e-3, 1e-3, size=(16, 16)); qs = rng.normal(8.5e-3, 5e-4, size=(16, 16))
+            av, ref = qt.mean(), rng.uniform(0, 2e-4)
+            f = lambda x, qt=qt, qs=qs, av=av, ref=ref: float(numpy.maximum(x * (qt - av) + av - qs, 0).sum() / 256 - ref)   # noqa: E731
+        else:
+            qt = rng.normal(8e-3, 1e-3, size=(8, 8)); qs = rng.normal(9.5e-3, 5e-4, size=(8, 8)); R = rng.normal(size=(8, 8))
+            ref = rng.uniform(0, 5e-4)
+            f = lambda x, qt=qt, qs=qs, R=R, ref=ref: float(numpy.maximum(qt + x * R * 1e-3 - qs, 0).sum() / 64 - ref)      # noqa: E731
+        try:
+            r1, info = brentq(f, 0, 5, full_output=True)
+        except ValueError:
+            with pytest.raises(ValueError):
+                vo.brentq_restated(f, 0, 5)
+            continue
+        r2, calls = vo.brentq_restated(f, 0, 5)
+        assert r1 == r2 and calls == info.function_calls, t
+        compared += 1
+    assert compared > 800
+
+
+def test_npsum_restatement_equals_ndarray_sum_bit_for_bit():
+    rng = numpy.random.default_rng(1)
+    for n in list(range(1, 300)) + [511, 512, 1000, 4095, 4096, 4097, 8191, 8192, 8193, 12345, 16384]:
+        a = rng.normal(size=n) * 10.0 ** rng.integers(-8, 8, size=n)
+        assert float(a.sum()) == vo.npsum_restated(a), n
+    a = numpy.maximum(rng.normal(size=(64, 64)) * 1.3 - 0.2, 0)      # the shape and expression class of get_ql_diff
+    assert float(a.sum()) == vo.npsum_restated(a)
+
+
+@pytest.mark.parametrize("constantT", [False, True])
+def test_oracle_does_what_the_algorithm_promises(constantT):
+    f = make_les_fields(16, 12, 40, seed=3)
+    numpy.random.seed(42)
+    R = vo.make_R(16, 12)
+    assert abs(R.sum()) < 1e-12
+    r = vo.variability_nudge(f["qt"], f["qsat"], f["ql_av"], f["qt_av"], f["presf"], f["ql_ref"], R, 900.0, constantT,
+                             thl=f["thl"], ql=f["ql"])
+    assert r["error"] is None
+    st = r["status"]
+    assert (st & 1).any() and (st & 2).any() and (st & 4).any() and (st == 0).any()      # every branch exercised
+    ql_new = numpy.maximum(r["qt"] - f["qsat"], 0).mean(axis=(0, 1))
+    for k in numpy.nonzero(((st & 1) != 0) & ((st & 4) == 0) & ((st & 8) == 0))[0]:                # multiplicative root:
+        assert abs(ql_new[k] - f["ql_ref"][k]) < 1e-9 * max(f["ql_ref"][k], 1e-6)                  # mean ql == ql_ref
+        assert abs(r["qt"][:, :, k].mean() - f["qt_av"][k]) < 1e-12                                # mean qt preserved
+    for k in numpy.nonzero((st & 4) != 0)[0]:                                                      # additive root
+        assert abs(ql_new[k] - f["ql_ref"][k]) < 1e-9 * max(f["ql_ref"][k], 1e-6) and r["beta"][k] == 1
+    for k in numpy.nonzero(st == 0)[0]:
+        assert numpy.array_equal(r["qt"][:, :, k], f["qt"][:, :, k]) and r["beta"][k] == 1
+    for k in numpy.nonzero(st == 2)[0]:                                                            # barely unsaturated
+        assert ql_new[k] <= f["ql_av"][k] * (1 + 1e-12)        # the plane is pulled toward saturation at its wettest point
+    assert numpy.array_equal(r["alpha"], numpy.log(r["beta"]) / 900.0)
+    if constantT:
+        touched = st != 0
+        assert not numpy.array_equal(r["thl"][:, :, touched], f["thl"][:, :, touched])
+        assert numpy.array_equal(r["thl"][:, :, ~touched], f["thl"][:, :, ~touched])
+    else:
+        assert r["thl"] is not None and numpy.array_equal(r["thl"], f["thl"])
+
+
+class FieldLES:
+    """minimal LES face for spcpl.variability_nudge: the getters of splib/spcpl.py:618-636 and a ``fields`` namespace"""
+
+    class _Fields:
+        pass
+
+    def __init__(self, f, ql_ref, grid_index=1):
+        self.f, self.ql_ref, self.grid_index = f, ql_ref, grid_index
+        self.fields = FieldLES._Fields()
+        self.itot, self.jtot, self.ktot = f["qt"].shape
+
+    def get_itot(self):
+        return self.itot
+
+    def get_jtot(self):
+        return self.jtot
+
+    def get_field(self, name):
+        return {"Qsat": self.f["qsat"], "QT": self.f["qt"], "THL": self.f["thl"], "QL": self.f["ql"]}[name].copy()
+
+    def get_profile(self, name):
+        return {"QL": self.f["ql_av"], "QT": self.f["qt_av"]}[name].copy()
+
+    def get_presf(self):
+        return self.f["presf"].copy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("constantT", [False, True])
+def test_kernel_matches_the_numpy_scipy_oracle(constantT):
+    """K6 (csrc/spc_vnudge.hpp) through the drop-in API against the oracle on 4 synthetic LES (two small planes with
+    odd extents: leaf tails of the pairwise sum; 64 x 64 x 160, the bundled DALES case; 96 x 96 planes: more than one
+    8192-element chunk): beta, a, the updated qt and qt_std BIT-exact, status equal; thl (constantT) within 8 ulp."""
+    from sp_coupler_amd import spcpl
+    spcpl.set_engine(None)
+    shapes = [(16, 12, 40, 3), (9, 7, 23, 4), (64, 64, 160, 5), (96, 96, 12, 6)]
+    for group in ([0, 1], [2], [3]):                    # one launch per extent (a launch has one plane geometry)
+        fs = [make_les_fields(*shapes[g][:3], seed=shapes[g][3]) for g in group]
+        if len(group) == 2:                             # same geometry needed inside one launch: pad the second to the first
+            fs[1] = make_les_fields(*shapes[group[0]][:3], seed=shapes[group[1]][3])
+        les = [FieldLES(f, f["ql_ref"].copy(), grid_index=i + 1) for i, f in enumerate(fs)]
+        numpy.random.seed(42)
+        got = spcpl.variability_nudge_batched(les, 900.0, constantT, write=False)
+        numpy.random.seed(42)
+        for m, f, g in zip(les, fs, got):
+            R = vo.make_R(m.itot, m.jtot)
+            r = vo.variability_nudge(f["qt"], f["qsat"], f["ql_av"], f["qt_av"], f["presf"], f["ql_ref"], R, 900.0,
+                                     constantT, thl=f["thl"], ql=f["ql"])
+            assert r["error"] is None
+            assert numpy.array_equal(g["status"], r["status"]), (g["status"], r["status"])
+            assert (r["status"] & 1).any() and (r["status"] & 4).any()
+            assert numpy.array_equal(g["beta"], r["beta"]) and numpy.array_equal(g["a"], r["a"])
+            assert numpy.array_equal(m.fields.QT, r["qt"])
+            assert numpy.array_equal(g["qt_std"], r["qt_std"]) and numpy.array_equal(g["alpha"], r["alpha"])
+            if constantT:
+                err = numpy.abs(m.fields.THL - r["thl"]).max()
+                assert err <= 8 * 2.220446049250313e-16 * numpy.abs(r["thl"]).max(), err
+                assert not numpy.array_equal(m.fields.THL, f["thl"])
+            else:
+                assert not hasattr(m.fields, "THL")
+
+
+@pytest.mark.gpu
+def test_no_sign_change_for_the_additive_noise_raises_like_scipy():
+    """Where scipy's brentq raises ValueError (the reference does not guard the additive search, spcpl.py:713) the
+    drop-in raises ValueError too, after the launch."""
+    from sp_coupler_amd import spcpl
+    spcpl.set_engine(None)
+    f = make_les_fields(8, 8, 10, seed=9)
+    f["ql_ref"][:] = 0.0
+    f["ql_ref"][4] = 50.0                  # no amount of noise a R, a in [0, 5], reaches a mean ql of 50
+    les = FieldLES(f, f["ql_ref"].copy())
+    numpy.random.seed(1)
+    with pytest.raises(ValueError, match="different signs"):
+        spcpl.variability_nudge(les, 900.0)
+    numpy.random.seed(1)
+    r = vo.variability_nudge(f["qt"], f["qsat"], f["ql_av"], f["qt_av"], f["presf"], f["ql_ref"], vo.make_R(8, 8), 900.0)
+    assert isinstance(r["error"], ValueError)

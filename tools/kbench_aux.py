@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Timing of the kernels off the default path: K4 (conservative coarsening, spc_backward_* with conservative=1),
+K5 (spifs diagnostics) and K6 (variability nudge).  HIP events around back-to-back launches; bytes = algorithmic.
+usage: python tools/kbench_aux.py [--sizes 1024,35718] [--levels 91,160] [--vn-cols 2,64]"""
+import argparse
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy  # noqa: E402
+import torch  # noqa: E402
+
+from sp_coupler_amd import synthetic  # noqa: E402
+from sp_coupler_amd.engine import Engine  # noqa: E402
+
+
+def timed(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sizes", default="1024,35718")
+    ap.add_argument("--levels", default="91,160")
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--vn-cols", default="2,64")
+    a = ap.parse_args()
+    nG, nL = (int(x) for x in a.levels.split(","))
+    eng = Engine("cuda:0")
+    sptr = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for n in (int(x) for x in a.sizes.split(",")):
+        gcm, zf, zh, prof = synthetic.make_batch_tiled(n, nG, nL, seed=77, couple_surface=False)
+        g = {k: torch.from_numpy(v).cuda() for k, v in gcm.items()}
+        p = {k: torch.from_numpy(v).cuda() for k, v in prof.items()}
+        zf_d, zh_d = torch.from_numpy(zf).cuda(), torch.from_numpy(zh).cuda()
+        k3 = eng.plan_backward(g, zf_d, p, 1.0, 900.0, Zf=None, want_start_index=False)
+        k4 = eng.plan_backward(g, zf_d, p, 1.0, 900.0, Zf=None, want_start_index=False, conservative=True, zh=zh_d)
+        t3 = timed(lambda: k3.launch_raw(sptr), a.iters)
+        t4 = timed(lambda: k4.launch_raw(sptr), a.iters)
+        b3 = n * ((9 * nG + 6 * nL) + 7 * nG) * 8
+        b4 = b3 + n * (nL + nG + 1) * 8                      # + Rhobf [nL], Zghalf [nG+1] per column
+        t5a = timed(lambda: eng.diagnostics(g), a.iters)
+        t5b = timed(lambda: eng.diagnostics(g, zf_d, p), a.iters)
+        b5a = n * ((6 * nG + nG + 1) + (4 * nG + nG + 1)) * 8          # reads T,SH,QL,QI,Pf,Zgfull,Zghalf; writes Tv,THL,QT,Zf,Zh
+        b5b = b5a + n * (3 * nL + 3 * nL) * 8                          # + reads THL,QL,QL_ice; writes pf,t,ql_water
+        print("n=%d %d<->%d | K3 %.1f us %.0f GB/s | K4 (conservative) %.1f us %.0f GB/s (%.2fx K3) | K5 gcm-level %.1f us %.0f GB/s | "
+              "K5 +les-level %.1f us %.0f GB/s" % (n, nG, nL, t3, b3 / t3 / 1e3, t4, b4 / t4 / 1e3, t4 / t3, t5a, b5a / t5a / 1e3,
+                                                 t5b, b5b / t5b / 1e3), flush=True)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from tests.test_vnudge import make_les_fields
+    for ncol in (int(x) for x in a.vn_cols.split(",")):
+        f = make_les_fields(64, 64, 160, seed=5)
+        rep = lambda x: torch.from_numpy(numpy.ascontiguousarray(numpy.broadcast_to(x, (ncol,) + x.shape))).cuda()     # noqa: E731
+        qt0, qsat, thl0, ql = rep(f["qt"]), rep(f["qsat"]), rep(f["thl"]), rep(f["ql"])
+        R = torch.from_numpy(numpy.random.default_rng(1).normal(size=(ncol, 64, 64))).cuda()
+        prof = {k: rep(f[k]) for k in ("ql_av", "qt_av", "ql_ref", "presf")}
+        qt = qt0.clone()
+
+        def run():
+            qt.copy_(qt0)
+            eng.variability_nudge(qt, qsat, R, prof["ql_av"], prof["qt_av"], prof["ql_ref"])
+        t = timed(run, 5)
+        tc = timed(lambda: qt.copy_(qt0), 5)
+        print("K6 variability nudge: %d LES of 64x64x160: %.0f us per launch (%.0f us of it the qt reset copy); "
+              "the reference's brentq over NumPy: see tests" % (ncol, t, tc), flush=True)
+
+
+if __name__ == "__main__":
+    main()

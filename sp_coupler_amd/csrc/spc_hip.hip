@@ -691,39 +691,8 @@ template <typename T, int NG, int NL, int WT> __global__ __launch_bounds__(BLOCK
 // K4 backward, conservative coarsening: splib/spcpl.py:479-489 -> sputils.interp_c / integral
 // (splib/sputils.py:94-189).  Same tendencies / masking as K3, but each GCM level receives the
 // rho-weighted mean of the piecewise-constant LES profile over [Zh[i+1], Zh[i]] instead of a linear
-// interpolation.  The sums reproduce numpy's pairwise summation (`ndarray.sum()`: 8 accumulators per
-// 128-block, halves split at multiples of 8) so results are bit-identical to the NumPy evaluation.
-// LDS per column: t | qt | ql | ql_ice | u | v | rho, each [nL]; Zf [nG]; Zh [nG+1]; then zf and zh
-// ([nL] each when the LES grid is shared, else [CB x nL] each).
+// interpolation.  Kernel: spc_k4.hpp (one thread per (level, field)).
 // =================================================================================================
-template <int D, typename F> __device__ __forceinline__ auto np_pairwise_sum(const F &term, int lo, int n) -> decltype(term(0))
-{
-    using T = decltype(term(0));
-    if (n < 8) {
-        T res = T(0);
-        for (int i = 0; i < n; ++i) res += term(lo + i);
-        return res;
-    }
-    if (n <= 128 || D == 0) {
-        T r0 = term(lo), r1 = term(lo + 1), r2 = term(lo + 2), r3 = term(lo + 3), r4 = term(lo + 4), r5 = term(lo + 5),
-          r6 = term(lo + 6), r7 = term(lo + 7);
-        int i = 8;
-        for (; i < n - (n % 8); i += 8) {
-            r0 += term(lo + i); r1 += term(lo + i + 1); r2 += term(lo + i + 2); r3 += term(lo + i + 3);
-            r4 += term(lo + i + 4); r5 += term(lo + i + 5); r6 += term(lo + i + 6); r7 += term(lo + i + 7);
-        }
-        T res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-        for (; i < n; ++i) res += term(lo + i);
-        return res;
-    }
-    if constexpr (D > 0) {
-        int n2 = n / 2;
-        n2 -= n2 % 8;
-        return np_pairwise_sum<D - 1>(term, lo, n2) + np_pairwise_sum<D - 1>(term, lo + n2, n - n2);
-    }
-    return T(0);
-}
-
 // first k in [1, n-1] with !(z[k] < a), minus 1: the `while z[i+1] < a: i += 1` scan of integral()
 // (splib/sputils.py:122-127) for ascending z
 template <typename T> __device__ __forceinline__ int scan_cell(const T *z, int n, T a)
@@ -736,112 +705,7 @@ template <typename T> __device__ __forceinline__ int scan_cell(const T *z, int n
     return lo - 1;
 }
 
-template <typename T> __global__ __launch_bounds__(BLOCK) void k_backward_cons(const BwdP<T> p)
-{
-    const DimsP &d = p.d;
-    const int nG = d.nG, nL = d.nL, cb = d.cb, tid = threadIdx.x;
-    const int64_t col0 = (int64_t)slab_index(d.xcd_remap) * cb;
-    const int ncol = (int)((d.n_cols - col0) < cb ? (d.n_cols - col0) : cb);
-    const size_t per_col = (size_t)7 * nL + nG + (nG + 1);
-    T *const lds = reinterpret_cast<T *>(spc_smem);
-    T *const lh = lds + (size_t)cb * per_col;                    // zf
-    T *const lzh = lh + (d.shared_grid ? nL : (size_t)cb * nL);  // zh
-    const int n1 = ncol * nG;
-
-    GcmIn<T> pre = {};
-    if (tid < n1) {
-        const int c = tid / nG, k = tid - c * nG;
-        const int64_t cg = (col0 + c) * d.pitchG;
-        pre = load_gcm(p, cg + k, cg + (nG - 1 - k));
-    }
-    for (int e = tid; e < ncol * nL; e += BLOCK) {
-        const int c = e / nL, l = e - c * nL;
-        const int64_t o = (col0 + c) * d.pitchL + l;
-        T *const s = lds + (size_t)c * per_col + l;
-        s[0] = p.t_d[o];
-        s[nL] = p.qt_d[o];
-        s[2 * nL] = p.ql_d[o];
-        s[3 * nL] = p.ql_ice_d[o];
-        s[4 * nL] = p.u_d[o];
-        s[5 * nL] = p.v_d[o];
-        s[6 * nL] = p.rhobf_d[o];
-        if (!d.shared_grid) { lh[e] = p.zf[o]; lzh[e] = p.zh[o]; }
-    }
-    if (d.shared_grid)
-        for (int e = tid; e < nL; e += BLOCK) { lh[e] = p.zf[e]; lzh[e] = p.zh[e]; }
-    for (int e = tid; e < ncol * (nG + 1); e += BLOCK) {
-        const int c = e / (nG + 1), k = e - c * (nG + 1);
-        const int64_t col = col0 + c, gh = col * d.pitchGh;
-        T *const s = lds + (size_t)c * per_col + 7 * nL;
-        s[nG + k] = p.Zh ? p.Zh[gh + k] : div_grav(p.Zghalf[gh + k] - p.Zghalf[gh + nG]);      // spcpl.py:197
-        if (k < nG) {
-            const int64_t g = col * d.pitchG + k;
-            s[k] = p.Zf ? p.Zf[g] : div_grav(p.Zgfull[g] - p.Zghalf[gh + nG]);                  // spcpl.py:198
-        }
-    }
-    __syncthreads();
-
-    for (int e = tid; e < n1; e += BLOCK) {
-        const int c = e / nG, k = e - c * nG;
-        const int64_t col = col0 + c, cg = col * d.pitchG, g = cg + k;
-        const T *const s = lds + (size_t)c * per_col;
-        const T *const h = d.shared_grid ? lh : lh + (size_t)c * nL;
-        const T *const z = d.shared_grid ? lzh : lzh + (size_t)c * nL;
-        const T *const Zf = s + 7 * nL, *const Zh = Zf + nG, *const w = s + 6 * nL;
-        const GcmIn<T> in = (e == tid) ? pre : load_gcm(p, g, cg + (nG - 1 - k));
-        const int start_index = ss_left_neg(Zf, nG, h[nL - 1]);                        // spcpl.py:498
-        T X0 = T(0), X1 = T(0), X2 = T(0), X3 = T(0), X4 = T(0), X5 = T(0), X6 = T(0);   // Q = zeros (sputils.py:185)
-        if (Zh[k] < z[nL - 1]) {                                                       // sputils.py:187
-            T a = Zh[k + 1], b = Zh[k];                                                // integral(ZZ[i+1], ZZ[i], ...)
-            if (a < z[0] || a > z[nL - 1] || b < z[0] || b > z[nL - 1]) {
-                // sputils.py:113-115 returns None and the reference then fails on `Q[i] = None`; here: NaN
-                X0 = X1 = X2 = X3 = X4 = X5 = X6 = T(0) / T(0);
-            } else {
-                T sign = T(1);
-                if (a > b) { sign = T(-1); const T t = a; a = b; b = t; }              // sputils.py:117-120
-                const int ia = scan_cell(z, nL, a);                                    // sputils.py:122-124
-                int ib = scan_cell(z, nL, b);                                          // sputils.py:125-127
-                if (ib < ia) ib = ia;
-                const int cnt = ib - ia + 1;
-                const T da = a - z[ia], db = z[ib + 1] - b;
-                const T Sw = np_pairwise_sum<2>([&](int i) { return w[i] * (z[i + 1] - z[i]); }, ia, cnt);   // :157
-                const T den = (Sw - w[ia] * da) - w[ib] * db;                          // sputils.py:159-161
-                // fields in the order of spcpl.py:482-488: t, qt, ql, ql_water (= ql - ql_ice, :402), ql_ice, u, v
-#pragma unroll 1
-                for (int f = 0; f < 7; ++f) {
-                    const T *const qa = s + (size_t)(f < 3 ? f : f - 1) * nL;
-                    const T *const qb = s + (size_t)3 * nL;
-                    const bool sub = (f == 3);
-                    auto q = [&](int i) { return sub ? qa[i] - qb[i] : qa[i]; };
-                    const T S = np_pairwise_sum<2>([&](int i) { return (w[i] * q(i)) * (z[i + 1] - z[i]); }, ia, cnt);
-                    const T Sa = (w[ia] * q(ia)) * da, Sb = (w[ib] * q(ib)) * db;      // sputils.py:154-155
-                    const T m = ((S - Sa) - Sb) / den * sign;                          // sputils.py:161
-                    X0 = f == 0 ? m : X0; X1 = f == 1 ? m : X1; X2 = f == 2 ? m : X2; X3 = f == 3 ? m : X3;
-                    X4 = f == 4 ? m : X4; X5 = f == 5 ? m : X5; X6 = f == 6 ? m : X6;
-                }
-            }
-        }
-        T f_T = p.factor * (X0 - in.tt) / p.dt;                                      // spcpl.py:518
-        T f_SH = p.factor * ((X1 - X2) - in.sh) / p.dt;                            // spcpl.py:519
-        T f_QL = p.factor * (X3 - in.ql) / p.dt;                                     // spcpl.py:520
-        T f_QI = p.factor * (X4 - in.qi) / p.dt;                                     // spcpl.py:521
-        T f_U = p.factor * (X5 - in.u) / p.dt;                                       // spcpl.py:524
-        T f_V = p.factor * (X6 - in.v) / p.dt;                                       // spcpl.py:525
-        T f_A = p.factor * (in.a_d - in.a) / p.dt;                                     // spcpl.py:526
-        if (k < start_index) {                                                         // spcpl.py:527-533
-            const T zero = T(0);
-            f_T *= zero; f_SH *= zero; f_QL *= zero; f_QI *= zero; f_U *= zero; f_V *= zero; f_A *= zero;
-        }
-        p.f_T[g] = f_T;
-        p.f_SH[g] = f_SH;
-        p.f_QL[g] = f_QL;
-        p.f_QI[g] = f_QI;
-        p.f_U[g] = f_U;
-        p.f_V[g] = f_V;
-        p.f_A[g] = f_A;
-        if (p.start_index && k == 0) p.start_index[col] = start_index;
-    }
-}
+#include "spc_k4.hpp"
 
 // =================================================================================================
 // K5 diagnostics: splib/spcpl.py:176, 197-198, 214-215 (GCM levels); 402, 408-409 (LES levels)
@@ -974,7 +838,7 @@ void lds_elems(const spc_dims *d, int pass, bool with_idx, size_t *per_col, size
     switch (pass) {
     case 0: *per_col = 6 * nG + ((with_idx && !sh) ? nL : 0); *fixed = (with_idx && sh) ? nL : 0; break;
     case 1: *per_col = 6 * nL + nG + (sh ? 0 : nL); *fixed = sh ? nL : 0; break;
-    case 4: *per_col = 7 * nL + 2 * nG + 1 + (sh ? 0 : 2 * nL); *fixed = sh ? 2 * nL : 0; break;
+    case 4: *per_col = 7 * (nL + 1) + 9 * nG + 1 + (sh ? 0 : 2 * nL); *fixed = sh ? 2 * nL : 0; break;
     case 2: *per_col = sh ? 0 : nL; *fixed = sh ? nL : 0; break;
     default: *per_col = 2 * nG; *fixed = 0; break;
     }
@@ -1294,19 +1158,18 @@ template <typename T> int backward_impl(const spc_dims *d, const spc_backward_ar
         REQUIRE(a->zh, "zh (conservative)"); REQUIRE(a->rhobf_d, "rhobf_d (conservative)");
         if (!a->Zh && !a->Zghalf) return fail(SPC_ERR_INVALID_ARGUMENT, "%sconservative: neither Zh nor Zghalf given");
         if (d->nL < 2) return fail(SPC_ERR_INVALID_ARGUMENT, "%sconservative coarsening needs nL >= 2");
-        if (d->nL > 513) return fail(SPC_ERR_UNSUPPORTED, "%sconservative coarsening supports nL <= 513 (pairwise-sum tree depth)");
     }
     const int geo = geometry_id(d);
     using KB = void (*)(const BwdP<T>);
     static const KB kb[2][4] = {
         {k_backward<T, 0, 0, 0>, k_backward<T, 91, 160, 0>, k_backward<T, 137, 512, 0>, k_backward<T, 19, 160, 0>},
         {k_backward<T, 0, 0, 1>, k_backward<T, 91, 160, 1>, k_backward<T, 137, 512, 1>, k_backward<T, 19, 160, 1>}};
-    const int cb = cons ? pick_cb(d, 4, false, sizeof(T), k_backward_cons<T>) : pick_cb(d, 1, false, sizeof(T), kb[0][geo]);
+    const int cb = cons ? pick_cb(d, 4, false, sizeof(T), k_backward_cons2<T>) : pick_cb(d, 1, false, sizeof(T), kb[0][geo]);
     const int wt = small_batch(d->n_cols * (int64_t)(7 * d->nG * sizeof(T)));
     size_t per_col, fixed;
     lds_elems(d, cons ? 4 : 1, false, &per_col, &fixed);
     const size_t smem = (per_col * cb + fixed) * sizeof(T);
-    if ((rc = cons ? ensure_lds(k_backward_cons<T>, smem, "backward (conservative)") : ensure_lds(kb[wt][geo], smem, "backward"))) return rc;
+    if ((rc = cons ? ensure_lds(k_backward_cons2<T>, smem, "backward (conservative)") : ensure_lds(kb[wt][geo], smem, "backward"))) return rc;
     BwdP<T> p;
     p.d = make_dims(d, cb);
     p.Tm = (const T *)a->T; CP(SH); CP(QL); CP(QI); CP(U); CP(V); CP(A); CP(Zf); CP(Zgfull); CP(Zghalf); CP(zf);
@@ -1324,7 +1187,7 @@ template <typename T> int backward_impl(const spc_dims *d, const spc_backward_ar
     }
     const unsigned grid = (unsigned)((d->n_cols + cb - 1) / cb);
     if (cons)
-        hipLaunchKernelGGL(k_backward_cons<T>, dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(k_backward_cons2<T>, dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(kb[wt][geo], dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
     return launch_status(cons ? "k_backward_cons" : "k_backward");
@@ -1454,7 +1317,7 @@ int spc_pick_cols_per_block(const spc_dims *d, int pass)
     case 1: return pick_cb(d, 1, false, sizeof(double), k_backward<double, 0, 0, 0>);
     case 2: return pick_cb(d, 2, true, sizeof(double), k_cloud_idx<double>);
     case 3: return pick_cb(d, 3, false, sizeof(double), k_diag<double>);
-    case 4: return pick_cb(d, 4, false, sizeof(double), k_backward_cons<double>);
+    case 4: return pick_cb(d, 4, false, sizeof(double), k_backward_cons2<double>);
     default: return fail(SPC_ERR_INVALID_ARGUMENT, "%spass must be 0..4");
     }
 }

@@ -1,0 +1,124 @@
+// spc_k4.hpp -- K4, second form: conservative coarsening (splib/spcpl.py:479-489 -> sputils.interp_c / integral,
+// splib/sputils.py:94-189) with ONE THREAD PER (GCM level, field).  The first form gave every GCM level to one
+// thread, which then ran eight numpy-ordered sums (the weight sum and seven fields) one after the other: 233
+// VGPRs, two waves per SIMD, long serial chains.  Here eight consecutive lanes share a level -- lanes 0..6 sum one
+// field each, lane 7 the weights -- so the eight sums of a level run side by side, the layer means go through
+// LDS, and a second, flat pass forms the seven tendencies with coalesced loads and stores exactly like K3.
+// Every sum is numpy's ndarray.sum() of the reference's temporary (vn_npsum: pairwise blocks of 128, 8
+// accumulators, 8192-element chunks), so any nL is supported and results stay bit-identical to the NumPy
+// evaluation.  LDS per column: q[7][nL+1] = t | qt | ql | ql_ice | u | v | rho (one element of padding per
+// field: a field stride of nL x 8 B = 0 mod 64 banks would put the eight lanes of a level on one bank), then
+// Zf[nG] | Zh[nG+1] | X[7][nG] (layer means); then zf and zh ([nL] each when shared, else [CB x nL] each).
+#pragma once
+
+template <typename T> __global__ __launch_bounds__(BLOCK) void k_backward_cons2(const BwdP<T> p)
+{
+    const DimsP &d = p.d;
+    const int nG = d.nG, nL = d.nL, cb = d.cb, tid = threadIdx.x, nLp = nL + 1;
+    const int64_t col0 = (int64_t)slab_index(d.xcd_remap) * cb;
+    const int ncol = (int)((d.n_cols - col0) < cb ? (d.n_cols - col0) : cb);
+    const size_t per_col = (size_t)7 * nLp + nG + (nG + 1) + (size_t)7 * nG;
+    T *const lds = reinterpret_cast<T *>(spc_smem);
+    T *const lh = lds + (size_t)cb * per_col;                    // zf
+    T *const lzh = lh + (d.shared_grid ? nL : (size_t)cb * nL);  // zh
+    const int n1 = ncol * nG;
+
+    // ---- stage the LES slab, the LES grids and the GCM heights ------------------------------------------------
+    for (int e = tid; e < ncol * nL; e += BLOCK) {
+        const int c = e / nL, l = e - c * nL;
+        const int64_t o = (col0 + c) * d.pitchL + l;
+        T *const s = lds + (size_t)c * per_col + l;
+        s[0] = p.t_d[o];
+        s[nLp] = p.qt_d[o];
+        s[2 * nLp] = p.ql_d[o];
+        s[3 * nLp] = p.ql_ice_d[o];
+        s[4 * nLp] = p.u_d[o];
+        s[5 * nLp] = p.v_d[o];
+        s[6 * nLp] = p.rhobf_d[o];
+        if (!d.shared_grid) { lh[e] = p.zf[o]; lzh[e] = p.zh[o]; }
+    }
+    if (d.shared_grid)
+        for (int e = tid; e < nL; e += BLOCK) { lh[e] = p.zf[e]; lzh[e] = p.zh[e]; }
+    for (int e = tid; e < ncol * (nG + 1); e += BLOCK) {
+        const int c = e / (nG + 1), k = e - c * (nG + 1);
+        const int64_t col = col0 + c, gh = col * d.pitchGh;
+        T *const s = lds + (size_t)c * per_col + 7 * nLp;
+        s[nG + k] = p.Zh ? p.Zh[gh + k] : div_grav(p.Zghalf[gh + k] - p.Zghalf[gh + nG]);      // spcpl.py:197
+        if (k < nG) {
+            const int64_t g = col * d.pitchG + k;
+            s[k] = p.Zf ? p.Zf[g] : div_grav(p.Zgfull[g] - p.Zghalf[gh + nG]);                  // spcpl.py:198
+        }
+    }
+    __syncthreads();
+
+    // ---- layer means: thread = (column, GCM level, field); lane&7 = field, 7 = the weight sum -------------------
+    for (int e = tid; e < n1 * 8; e += BLOCK) {
+        const int f = e & 7, ck = e >> 3, c = ck / nG, k = ck - c * nG;
+        T *const s = lds + (size_t)c * per_col;
+        const T *const z = d.shared_grid ? lzh : lzh + (size_t)c * nL;
+        const T *const Zh = s + 7 * nLp + nG, *const w = s + 6 * nLp;
+        T X = T(0);                                                                    // Q = zeros (sputils.py:185)
+        if (Zh[k] < z[nL - 1]) {                                                       // sputils.py:187
+            T a = Zh[k + 1], b = Zh[k];                                                // integral(ZZ[i+1], ZZ[i], ...)
+            if (a < z[0] || a > z[nL - 1] || b < z[0] || b > z[nL - 1]) {
+                X = T(0) / T(0);       // sputils.py:113-115 returns None; Q[i] = None stores NaN (numpy 2.x)
+            } else {
+                T sign = T(1);
+                if (a > b) { sign = T(-1); const T t = a; a = b; b = t; }              // sputils.py:117-120
+                const int ia = scan_cell(z, nL, a);                                    // sputils.py:122-124
+                int ib = scan_cell(z, nL, b);                                          // sputils.py:125-127
+                if (ib < ia) ib = ia;
+                const int cnt = ib - ia + 1;
+                const T da = a - z[ia], db = z[ib + 1] - b;
+                // fields in the order of spcpl.py:482-488: t, qt, ql, ql_water (= ql - ql_ice, :402), ql_ice, u, v
+                const T *const qa = s + (size_t)(f < 3 ? f : (f < 7 ? f - 1 : 0)) * nLp;
+                const T *const qb = s + (size_t)3 * nLp;
+                const bool sub = (f == 3), wsum = (f == 7);
+                auto q = [&](int i) { return sub ? qa[i] - qb[i] : qa[i]; };
+                const T S = vn_npsum([&](int i) {
+                    const T dz = z[ia + i + 1] - z[ia + i];
+                    return wsum ? w[ia + i] * dz : (w[ia + i] * q(ia + i)) * dz;       // sputils.py:152 / 157
+                }, cnt);
+                const T ea = wsum ? w[ia] * da : (w[ia] * q(ia)) * da;                 // Sa / Swa, sputils.py:154,159
+                const T eb = wsum ? w[ib] * db : (w[ib] * q(ib)) * db;                 // Sb / Swb
+                const T num = (S - ea) - eb;
+                const T den = __shfl(num, (threadIdx.x & 63) | 7);                     // the level's weight lane
+                X = num / den * sign;                                                  // sputils.py:161
+            }
+        }
+        if (f < 7) s[7 * nLp + nG + (nG + 1) + (size_t)f * nG + k] = X;
+    }
+    __syncthreads();
+
+    // ---- tendencies: flat over the [ncol x nG] slab, as K3 (spcpl.py:498, 518-533) -----------------------------
+    for (int e = tid; e < n1; e += BLOCK) {
+        const int c = e / nG, k = e - c * nG;
+        const int64_t col = col0 + c, cg = col * d.pitchG, g = cg + k;
+        const T *const s = lds + (size_t)c * per_col;
+        const T *const h = d.shared_grid ? lh : lh + (size_t)c * nL;
+        const T *const Zf = s + 7 * nLp, *const X = Zf + nG + (nG + 1);
+        const GcmIn<T> in = load_gcm(p, g, cg + (nG - 1 - k));
+        const int start_index = ss_left_neg(Zf, nG, h[nL - 1]);                        // spcpl.py:498
+        const T X0 = X[k], X1 = X[nG + k], X2 = X[2 * nG + k], X3 = X[3 * nG + k], X4 = X[4 * nG + k], X5 = X[5 * nG + k],
+                X6 = X[6 * nG + k];
+        T f_T = p.factor * (X0 - in.tt) / p.dt;                                        // spcpl.py:518
+        T f_SH = p.factor * ((X1 - X2) - in.sh) / p.dt;                                // spcpl.py:519
+        T f_QL = p.factor * (X3 - in.ql) / p.dt;                                       // spcpl.py:520
+        T f_QI = p.factor * (X4 - in.qi) / p.dt;                                       // spcpl.py:521
+        T f_U = p.factor * (X5 - in.u) / p.dt;                                         // spcpl.py:524
+        T f_V = p.factor * (X6 - in.v) / p.dt;                                         // spcpl.py:525
+        T f_A = p.factor * (in.a_d - in.a) / p.dt;                                     // spcpl.py:526
+        if (k < start_index) {                                                         // spcpl.py:527-533
+            const T zero = T(0);
+            f_T *= zero; f_SH *= zero; f_QL *= zero; f_QI *= zero; f_U *= zero; f_V *= zero; f_A *= zero;
+        }
+        p.f_T[g] = f_T;
+        p.f_SH[g] = f_SH;
+        p.f_QL[g] = f_QL;
+        p.f_QI[g] = f_QI;
+        p.f_U[g] = f_U;
+        p.f_V[g] = f_V;
+        p.f_A[g] = f_A;
+        if (p.start_index && k == 0) p.start_index[col] = start_index;
+    }
+}

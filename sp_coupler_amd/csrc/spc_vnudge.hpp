@@ -33,21 +33,22 @@ struct VnPlane {
 };
 
 // numpy pairwise_sum over elements [lo, lo+n) of term(ij), n <= 128: 8 accumulators, then the tail
-template <typename F> __device__ __forceinline__ double vn_leaf(const F &term, int lo, int n)
+template <typename F> __device__ __forceinline__ auto vn_leaf(const F &term, int lo, int n) -> decltype(term(0))
 {
+    using T = decltype(term(0));
     if (n < 8) {
-        double res = 0.0;
+        T res = T(0);
         for (int i = 0; i < n; ++i) res += term(lo + i);
         return res;
     }
-    double r0 = term(lo), r1 = term(lo + 1), r2 = term(lo + 2), r3 = term(lo + 3), r4 = term(lo + 4), r5 = term(lo + 5),
-           r6 = term(lo + 6), r7 = term(lo + 7);
+    T r0 = term(lo), r1 = term(lo + 1), r2 = term(lo + 2), r3 = term(lo + 3), r4 = term(lo + 4), r5 = term(lo + 5),
+      r6 = term(lo + 6), r7 = term(lo + 7);
     int i = 8;
     for (; i < n - (n % 8); i += 8) {
         r0 += term(lo + i); r1 += term(lo + i + 1); r2 += term(lo + i + 2); r3 += term(lo + i + 3);
         r4 += term(lo + i + 4); r5 += term(lo + i + 5); r6 += term(lo + i + 6); r7 += term(lo + i + 7);
     }
-    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    T res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
     for (; i < n; ++i) res += term(lo + i);
     return res;
 }
@@ -55,15 +56,16 @@ template <typename F> __device__ __forceinline__ double vn_leaf(const F &term, i
 // ndarray.sum() of term(0..n-1): 0.0 + sum over 8192-element chunks of the pairwise recursion
 // (pairwise_sum(a, n): n <= 128 -> leaf; else n2 = n/2 - (n/2)%8, pairwise(a, n2) + pairwise(a+n2, n-n2)),
 // evaluated depth first with an explicit stack (depth <= 7 inside a chunk: 8191 -> 4103 -> 2055 -> 1031 -> 519 -> 263 -> 135 -> 71).
-template <typename F> __device__ __forceinline__ double vn_npsum(const F &term, int n)
+template <typename F> __device__ __forceinline__ auto vn_npsum(const F &term, int n) -> decltype(term(0))
 {
-    double total = 0.0;
+    using T = decltype(term(0));
+    T total = T(0);
     for (int c0 = 0; c0 < n; c0 += 8192) {
         int cur_lo = c0, cur_n = (n - c0) < 8192 ? (n - c0) : 8192;
         int r_lo[10], r_n[10], depth = 0;
-        double left[10];
+        T left[10];
         bool has_left[10];
-        double v;
+        T v;
         for (;;) {
             while (cur_n > 128) {                       // descend into the left halves
                 int n2 = cur_n / 2;

@@ -75,10 +75,11 @@ template <typename T> __global__ __launch_bounds__(BLOCK) void k_backward_cons2(
                 const T *const qb = s + (size_t)3 * nLp;
                 const bool sub = (f == 3), wsum = (f == 7);
                 auto q = [&](int i) { return sub ? qa[i] - qb[i] : qa[i]; };
-                const T S = vn_npsum([&](int i) {
+                auto term = [&](int i) {
                     const T dz = z[ia + i + 1] - z[ia + i];
                     return wsum ? w[ia + i] * dz : (w[ia + i] * q(ia + i)) * dz;       // sputils.py:152 / 157
-                }, cnt);
+                };
+                const T S = cnt <= 128 ? T(0) + vn_leaf(term, 0, cnt) : vn_npsum(term, cnt);
                 const T ea = wsum ? w[ia] * da : (w[ia] * q(ia)) * da;                 // Sa / Swa, sputils.py:154,159
                 const T eb = wsum ? w[ib] * db : (w[ib] * q(ib)) * db;                 // Sb / Swb
                 const T num = (S - ea) - eb;

@@ -88,6 +88,13 @@ template <typename F> __device__ __forceinline__ auto vn_npsum(const F &term, in
     return total;
 }
 
+// the same, kept out of line: callers whose sums almost never exceed one 128-element block (K4: cells per GCM layer)
+// take vn_leaf directly and pay the recursion's registers and scratch only in the rare case
+template <typename F> __device__ __attribute__((noinline)) auto vn_npsum_outlined(const F &term, int n) -> decltype(term(0))
+{
+    return vn_npsum(term, n);
+}
+
 // get_ql_diff(beta) (spcpl.py:646-648) / get_ql_diff_additive(a) (spcpl.py:653-656)
 template <bool ADD> __device__ __forceinline__ double vn_ql_diff(const VnPlane &pl, double x, double ql_ref)
 {

@@ -269,10 +269,10 @@ def test_conservative_coarsening_bit_exact(eng, n, nG, nL, per_col):
 
 
 def test_conservative_coarsening_thick_layers_recursive_pairwise_sums(eng):
-    """GCM layers that span hundreds of LES cells (2 m LES spacing): ndarray.sum() then recurses (blocks of 128, halves
+    """GCM layers that span hundreds of LES cells (1 m LES spacing): ndarray.sum() then recurses (blocks of 128, halves
     split at multiples of 8); the kernel's sums must follow.  Round 1 refused nL > 513; any nL that fits LDS works now."""
     gcm, zf, zh, prof = synthetic.make_batch(12, 91, 2000, seed=52)
-    zf, zh = numpy.ascontiguousarray(zf * 0.2), numpy.ascontiguousarray(zh * 0.2)          # 2 m cells, top at 4 km
+    zf, zh = numpy.ascontiguousarray(zf * 0.1), numpy.ascontiguousarray(zh * 0.1)          # 1 m cells, top at 2 km
     g, p = to_dev(gcm, eng.device), to_dev(prof, eng.device)
     zf_d, zh_d = torch.from_numpy(zf).to(eng.device), torch.from_numpy(zh).to(eng.device)
     got = eng.backward(g, zf_d, p, FACTOR, DT, Zf=None, conservative=True, zh=zh_d)

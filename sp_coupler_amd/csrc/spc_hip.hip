@@ -986,7 +986,7 @@ V2Choice v2_pick(const char *env, int pass, int64_t n_cols, int nG, int nL)
     if (env_pair(env, &c.cb, &c.block)) return c;
     c.cb = 0; c.block = 0;
     if (nG == 91 && nL == 160) {
-        if (pass == 0 && n_cols >= 6000 && n_cols <= 65000) c = V2Choice{2, 192};
+        if (pass == 0 && n_cols >= 6000 && n_cols <= 100000) c = V2Choice{2, 192};
         if (pass == 1 && n_cols >= 200000) c = V2Choice{8, 512};
     }
     return c;
@@ -1000,11 +1000,12 @@ int launch_fwd_v2(const spc_dims *d, FwdP<double, false> &p, int wt, hipStream_t
     p.d = make_dims(d, CB);
     p.d.xcd_remap = env_int("SPC_V2_REMAP", 1);
     const unsigned grid = (unsigned)((d->n_cols + CB - 1) / CB);
-    auto k0 = k_forward_v2<NG, NL, CB, BLOCK_, 0>;
-    auto k1 = k_forward_v2<NG, NL, CB, BLOCK_, 1>;
-    int rc = ensure_lds(wt ? k1 : k0, smem, "forward");
+    // store / load policy: write-through for small launches, else non-temporal streaming (SPC_V2_NT=0: plain)
+    const int mode = wt ? 1 : (env_int("SPC_V2_NT", 1) ? 2 : 0);
+    auto kern = mode == 1 ? k_forward_v2<NG, NL, CB, BLOCK_, 1> : (mode == 2 ? k_forward_v2<NG, NL, CB, BLOCK_, 2> : k_forward_v2<NG, NL, CB, BLOCK_, 0>);
+    int rc = ensure_lds(kern, smem, "forward");
     if (rc) return rc;
-    hipLaunchKernelGGL(wt ? k1 : k0, dim3(grid), dim3(BLOCK_), smem, stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK_), smem, stream, p);
     return launch_status("k_forward_v2");
 }
 
@@ -1015,11 +1016,11 @@ int launch_bwd_v2(const spc_dims *d, BwdP<double> &p, int wt, hipStream_t stream
     p.d = make_dims(d, CB);
     p.d.xcd_remap = env_int("SPC_V2_REMAP", 1);
     const unsigned grid = (unsigned)((d->n_cols + CB - 1) / CB);
-    auto k0 = k_backward_v2<NG, NL, CB, BLOCK_, 0>;
-    auto k1 = k_backward_v2<NG, NL, CB, BLOCK_, 1>;
-    int rc = ensure_lds(wt ? k1 : k0, smem, "backward");
+    const int mode = wt ? 1 : (env_int("SPC_V2_NT_K3", 0) ? 2 : 0);      // K3: non-temporal measured neutral to worse
+    auto kern = mode == 1 ? k_backward_v2<NG, NL, CB, BLOCK_, 1> : (mode == 2 ? k_backward_v2<NG, NL, CB, BLOCK_, 2> : k_backward_v2<NG, NL, CB, BLOCK_, 0>);
+    int rc = ensure_lds(kern, smem, "backward");
     if (rc) return rc;
-    hipLaunchKernelGGL(wt ? k1 : k0, dim3(grid), dim3(BLOCK_), smem, stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK_), smem, stream, p);
     return launch_status("k_backward_v2");
 }
 

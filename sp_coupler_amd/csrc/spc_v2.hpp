@@ -21,25 +21,33 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 // 16-B load of flat elements (e, e+1) of a slab holding `lim` valid elements; the tail element of an odd-sized
 // last slab is fetched alone, nothing is read beyond `lim`.
-__device__ __forceinline__ d2 ld2(const double *q, int e, int lim)
+// MODE (the kernels' WT parameter): 0 plain, 1 write-through stores (small launches), 2 non-temporal loads AND
+// stores (streamed once: measured -2...-6.5 % on K1 between ~4k and ~100k columns, profiles/r02_nt_ab.log).
+template <int MODE = 0> __device__ __forceinline__ d2 ld2(const double *q, int e, int lim)
 {
     d2 r = {0.0, 0.0};
-    if (e + 1 < lim) r = *reinterpret_cast<const d2 *>(q + e);
-    else if (e < lim) r.x = q[e];
+    if (e + 1 < lim) {
+        if constexpr (MODE == 2 || SPC_NT == 1) r = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(q + e));
+        else r = *reinterpret_cast<const d2 *>(q + e);
+    } else if (e < lim) {
+        r.x = ldg(q + e);
+    }
     return r;
 }
 
 template <int WT> __device__ __forceinline__ void st2(double *q, int e, int lim, d2 v)
 {
     if (e + 1 < lim) {
-        if constexpr (WT == 1) {
+        if constexpr (WT == 2 || SPC_NT == 1) {
+            __builtin_nontemporal_store(v, reinterpret_cast<d2 *>(q + e));
+        } else if constexpr (WT == 1) {
             // write-through (sc1) 16-B store: nothing stays dirty in L2 for the end-of-kernel release
             asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(q + e), "v"(v) : "memory");
         } else {
             *reinterpret_cast<d2 *>(q + e) = v;
         }
     } else if (e < lim) {
-        stg<WT>(q + e, v.x);
+        stg<(WT == 1 ? 1 : 0)>(q + e, v.x);
     }
 }
 
@@ -104,14 +112,14 @@ __global__ __launch_bounds__(BLOCK) void k_forward_v2(const FwdP<double, false> 
 #pragma unroll
     for (int it = 0; it < IT1; ++it) {
         const int e = 2 * (tid + it * BLOCK);
-        gZg[it] = ld2(p.Zgfull + g0, e, lim1);
-        gPf[it] = ld2(p.Pf + g0, e, lim1);
-        gT[it] = ld2(p.Tm + g0, e, lim1);
-        gQL[it] = ld2(p.QL + g0, e, lim1);
-        gQI[it] = ld2(p.QI + g0, e, lim1);
-        gSH[it] = ld2(p.SH + g0, e, lim1);
-        gU[it] = ld2(p.U + g0, e, lim1);
-        gV[it] = ld2(p.V + g0, e, lim1);
+        gZg[it] = ld2<WT>(p.Zgfull + g0, e, lim1);
+        gPf[it] = ld2<WT>(p.Pf + g0, e, lim1);
+        gT[it] = ld2<WT>(p.Tm + g0, e, lim1);
+        gQL[it] = ld2<WT>(p.QL + g0, e, lim1);
+        gQI[it] = ld2<WT>(p.QI + g0, e, lim1);
+        gSH[it] = ld2<WT>(p.SH + g0, e, lim1);
+        gU[it] = ld2<WT>(p.U + g0, e, lim1);
+        gV[it] = ld2<WT>(p.V + g0, e, lim1);
         const int c0 = e / NG, c1 = (e + 1) / NG;
         zs0[it] = e < lim1 ? p.Zghalf[h0 + (int64_t)c0 * (NG + 1) + NG] : 0.0;           // spcpl.py:197-198
         zs1[it] = e + 1 < lim1 ? p.Zghalf[h0 + (int64_t)c1 * (NG + 1) + NG] : 0.0;
@@ -123,12 +131,12 @@ __global__ __launch_bounds__(BLOCK) void k_forward_v2(const FwdP<double, false> 
         // no GCM items
         const int e = 2 * (it * BLOCK + ((it & 1) ? BLOCK - 1 - tid : tid));
         const int l = e % NL;
-        lh[it] = d.shared_grid ? ld2(p.zf, l, NL) : ld2(p.zf + o0, e, lim2);              // spcpl.py:222
-        lu[it] = ld2(p.u_d + o0, e, lim2);
-        lv[it] = ld2(p.v_d + o0, e, lim2);
-        lthl[it] = ld2(p.thl_d + o0, e, lim2);
-        lqt[it] = ld2(p.qt_d + o0, e, lim2);
-        lql[it] = ld2(p.ql_d + o0, e, lim2);
+        lh[it] = d.shared_grid ? ld2<0>(p.zf, l, NL) : ld2<WT>(p.zf + o0, e, lim2);              // spcpl.py:222
+        lu[it] = ld2<WT>(p.u_d + o0, e, lim2);
+        lv[it] = ld2<WT>(p.v_d + o0, e, lim2);
+        lthl[it] = ld2<WT>(p.thl_d + o0, e, lim2);
+        lqt[it] = ld2<WT>(p.qt_d + o0, e, lim2);
+        lql[it] = ld2<WT>(p.ql_d + o0, e, lim2);
     }
     double xzgh[ITX], xzs[ITX];
     if (want_idx) {
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(BLOCK) void k_forward_v2(const FwdP<double, false> 
         }
         const int nz = d.shared_grid ? NL : lim2;                                         // LES half levels -> LDS
         for (int e = 2 * tid; e < nz; e += 2 * BLOCK)
-            *reinterpret_cast<d2 *>(lzh + e) = d.shared_grid ? ld2(p.zh, e, NL) : ld2(p.zh + o0, e, lim2);
+            *reinterpret_cast<d2 *>(lzh + e) = d.shared_grid ? ld2<0>(p.zh, e, NL) : ld2<WT>(p.zh + o0, e, lim2);
     }
     const int sc = BLOCK - 1 - tid;                    // the LAST threads own the per-column scalars
     double sc_ps = 0.0, sc_psd = 0.0;
@@ -177,7 +185,7 @@ __global__ __launch_bounds__(BLOCK) void k_forward_v2(const FwdP<double, false> 
     }
     __syncthreads();
 
-    if (sc < ncol) stg<WT>(&p.f_ps[col0 + sc], SPC_DIV(p.factor * (sc_ps - sc_psd), p.dt));       // spcpl.py:332
+    if (sc < ncol) stg<(WT == 1 ? 1 : 0)>(&p.f_ps[col0 + sc], SPC_DIV(p.factor * (sc_ps - sc_psd), p.dt));       // spcpl.py:332
 
     // ---- two LES levels per thread: 5 fields each, forcings, 16-B stores --------------------------------------
 #pragma unroll
@@ -241,17 +249,17 @@ __global__ __launch_bounds__(BLOCK) void k_backward_v2(const BwdP<double> p)
 #pragma unroll
     for (int it = 0; it < IT2; ++it) {
         const int e = 2 * (it * BLOCK + ((it & 1) ? BLOCK - 1 - tid : tid));
-        st[it] = ld2(p.t_d + o0, e, lim2);
-        sqt[it] = ld2(p.qt_d + o0, e, lim2);
-        sql[it] = ld2(p.ql_d + o0, e, lim2);
-        sqi[it] = ld2(p.ql_ice_d + o0, e, lim2);
-        su[it] = ld2(p.u_d + o0, e, lim2);
-        sv[it] = ld2(p.v_d + o0, e, lim2);
+        st[it] = ld2<WT>(p.t_d + o0, e, lim2);
+        sqt[it] = ld2<WT>(p.qt_d + o0, e, lim2);
+        sql[it] = ld2<WT>(p.ql_d + o0, e, lim2);
+        sqi[it] = ld2<WT>(p.ql_ice_d + o0, e, lim2);
+        su[it] = ld2<WT>(p.u_d + o0, e, lim2);
+        sv[it] = ld2<WT>(p.v_d + o0, e, lim2);
     }
     {
         const int nz = d.shared_grid ? NL : lim2;
         for (int e = 2 * tid; e < nz; e += 2 * BLOCK)
-            *reinterpret_cast<d2 *>(lh + e) = d.shared_grid ? ld2(p.zf, e, NL) : ld2(p.zf + o0, e, lim2);
+            *reinterpret_cast<d2 *>(lh + e) = d.shared_grid ? ld2<0>(p.zf, e, NL) : ld2<WT>(p.zf + o0, e, lim2);
     }
     d2 gZ[IT1], gT[IT1], gSH[IT1], gQL[IT1], gQI[IT1], gU[IT1], gV[IT1], gA[IT1];
     double ad0[IT1], ad1[IT1];
@@ -260,20 +268,20 @@ __global__ __launch_bounds__(BLOCK) void k_backward_v2(const BwdP<double> p)
         const int e = 2 * (tid + it * BLOCK);
         const int c0 = e / NG, c1 = (e + 1) / NG;
         if (p.Zf) {
-            gZ[it] = ld2(p.Zf + g0, e, lim1);
+            gZ[it] = ld2<WT>(p.Zf + g0, e, lim1);
         } else {                                                                           // spcpl.py:198
-            const d2 zg = ld2(p.Zgfull + g0, e, lim1);
+            const d2 zg = ld2<WT>(p.Zgfull + g0, e, lim1);
             const double z0 = e < lim1 ? p.Zghalf[h0 + (int64_t)c0 * (NG + 1) + NG] : 0.0;
             const double z1 = e + 1 < lim1 ? p.Zghalf[h0 + (int64_t)c1 * (NG + 1) + NG] : 0.0;
             gZ[it] = d2{div_grav(zg.x - z0), div_grav(zg.y - z1)};
         }
-        gT[it] = ld2(p.Tm + g0, e, lim1);
-        gSH[it] = ld2(p.SH + g0, e, lim1);
-        gQL[it] = ld2(p.QL + g0, e, lim1);
-        gQI[it] = ld2(p.QI + g0, e, lim1);
-        gU[it] = ld2(p.U + g0, e, lim1);
-        gV[it] = ld2(p.V + g0, e, lim1);
-        gA[it] = ld2(p.A + g0, e, lim1);
+        gT[it] = ld2<WT>(p.Tm + g0, e, lim1);
+        gSH[it] = ld2<WT>(p.SH + g0, e, lim1);
+        gQL[it] = ld2<WT>(p.QL + g0, e, lim1);
+        gQI[it] = ld2<WT>(p.QI + g0, e, lim1);
+        gU[it] = ld2<WT>(p.U + g0, e, lim1);
+        gV[it] = ld2<WT>(p.V + g0, e, lim1);
+        gA[it] = ld2<WT>(p.A + g0, e, lim1);
         // profile["A"][::-1] (spcpl.py:404): element (c, k) pairs with A_prof[c][NG-1-k]
         ad0[it] = e < lim1 ? p.A_prof[g0 + (int64_t)c0 * NG + (NG - 1 - (e - c0 * NG))] : 0.0;
         ad1[it] = e + 1 < lim1 ? p.A_prof[g0 + (int64_t)c1 * NG + (NG - 1 - (e + 1 - c1 * NG))] : 0.0;

@@ -290,6 +290,8 @@ template <typename T, bool FULL> struct FwdP {
     typename std::conditional<FULL, FwdOpt<T>, Empty>::type o;
 };
 
+template <typename T> using FwdFull = FwdP<T, true>;
+
 template <typename T> struct BwdP {
     DimsP d;
     const T *Tm, *SH, *QL, *QI, *U, *V, *A, *Zf, *Zgfull, *Zghalf, *zf;
@@ -379,6 +381,10 @@ template <typename T, bool FULL, int NG, int NL, int WT>
 __global__ __launch_bounds__(BLOCK, SPC_K1_WAVES) void k_forward(const FwdP<T, FULL> p)
 {
     const DimsP &d = p.d;
+    // The ~20 optional pointers of the FULL variant are fetched from the kernarg block where they are used (a
+    // volatile scalar load each) instead of living in SGPRs for the whole kernel: 68 -> few SGPR spills.
+#define OPT(f) (*(decltype(FwdOpt<T>::f) const volatile __attribute__((address_space(4))) *)( \
+    (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(FwdFull<T>, o) + offsetof(FwdOpt<T>, f)))
     const int nG = NG ? NG : d.nG, nL = NL ? NL : d.nL, cb = d.cb;
     const int64_t pitchG = NG ? NG : d.pitchG, pitchGh = NG ? NG + 1 : d.pitchGh, pitchL = NL ? NL : d.pitchL;
     const int p2G = NG ? cfloor_pow2(NG ? NG : 1) : d.p2G;
@@ -412,7 +418,7 @@ __global__ __launch_bounds__(BLOCK, SPC_K1_WAVES) void k_forward(const FwdP<T, F
         sc_ps = ldg(&p.Ph[(col0 + sc) * pitchGh + nG]);                                   // spcpl.py:246
         sc_psd = ldg(&p.ps_d[col0 + sc]);
         if constexpr (FULL)
-            if (p.o.rainrate) { sc_rain = p.o.rain[col0 + sc]; sc_rl = p.o.rain_last[col0 + sc]; }
+            if (OPT(rainrate)) { sc_rain = OPT(rain)[col0 + sc]; sc_rl = OPT(rain_last)[col0 + sc]; }
     }
     if (p.idx) {  // stage the LES half levels for the fused index map
         const int nz = d.shared_grid ? nL : n2;
@@ -438,7 +444,7 @@ __global__ __launch_bounds__(BLOCK, SPC_K1_WAVES) void k_forward(const FwdP<T, F
         s[4 * nG] = uu;
         s[5 * nG] = vv;
         if constexpr (FULL)
-            if (p.o.Zf) p.o.Zf[g] = zf_k;                                             // spcpl.py:200
+            if (OPT(Zf)) OPT(Zf)[g] = zf_k;                                             // spcpl.py:200
         const T iex = spc_pow(div_pref0(pf), (-K<T>::rd) / K<T>::cp);                 // sputils.py:34
         s[nG] = (tt - div_cp(K<T>::rlv * (ql + qi))) * iex;                           // spcpl.py:214
     }
@@ -451,15 +457,15 @@ __global__ __launch_bounds__(BLOCK, SPC_K1_WAVES) void k_forward(const FwdP<T, F
         const int64_t col = col0 + sc;
         stg<WT>(&p.f_ps[col], p.factor * (sc_ps - sc_psd) / p.dt);          // spcpl.py:332
         if constexpr (FULL) {
-            if (p.o.ps) p.o.ps[col] = sc_ps;
-            if (p.o.rainrate) p.o.rainrate[col] = (sc_rain - sc_rl) / p.dt;   // spcpl.py:325
-            if (p.o.wthl) {                                                            // spcpl.py:136-167
+            if (OPT(ps)) OPT(ps)[col] = sc_ps;
+            if (OPT(rainrate)) OPT(rainrate)[col] = (sc_rain - sc_rl) / p.dt;   // spcpl.py:325
+            if (OPT(wthl)) {                                                            // spcpl.py:136-167
                 const T rho = sc_ps / (K<T>::rd * ldg(&p.Tm[col * pitchG + nG - 1]));      // spcpl.py:153
-                p.o.wqt[col] = -(p.o.QLflux[col] + p.o.QIflux[col] + p.o.SHflux[col]) / rho;     // spcpl.py:159
-                p.o.wthl[col] = -p.o.TSflux[col] * spc_pow(div_pref0(sc_ps), (-K<T>::rd) / K<T>::cp)
+                OPT(wqt)[col] = -(OPT(QLflux)[col] + OPT(QIflux)[col] + OPT(SHflux)[col]) / rho;     // spcpl.py:159
+                OPT(wthl)[col] = -OPT(TSflux)[col] * spc_pow(div_pref0(sc_ps), (-K<T>::rd) / K<T>::cp)
                                 / (K<T>::cp * rho);                                    // spcpl.py:161
-                if (p.o.z0m) p.o.z0m[col] = p.o.Z0M[col];
-                if (p.o.z0h) p.o.z0h[col] = p.o.Z0H[col];
+                if (OPT(z0m)) OPT(z0m)[col] = OPT(Z0M)[col];
+                if (OPT(z0h)) OPT(z0h)[col] = OPT(Z0H)[col];
             }
         }
     }
@@ -487,10 +493,10 @@ __global__ __launch_bounds__(BLOCK, SPC_K1_WAVES) void k_forward(const FwdP<T, F
             stg<WT>(&p.f_ql[o], p.factor * (ql - in.qld) / p.dt);            // spcpl.py:333
             stg<WT>(&p.ql_ref[o], ql);                                                         // spcpl.py:347-348
             if constexpr (FULL) {
-                if (p.o.u) p.o.u[o] = u;
-                if (p.o.v) p.o.v[o] = v;
-                if (p.o.thl) p.o.thl[o] = thl;
-                if (p.o.qt) p.o.qt[o] = qt;
+                if (OPT(u)) OPT(u)[o] = u;
+                if (OPT(v)) OPT(v)[o] = v;
+                if (OPT(thl)) OPT(thl)[o] = thl;
+                if (OPT(qt)) OPT(qt)[o] = qt;
             }
         } else {                                                                      // fused K2, spcpl.py:764
             const int ei = e - n2, c = ei / nG, m = ei - c * nG;
@@ -506,15 +512,16 @@ __global__ __launch_bounds__(BLOCK, SPC_K1_WAVES) void k_forward(const FwdP<T, F
 
     // ---- half-level heights (optional output): spcpl.py:197 --------------------------------------
     if constexpr (FULL) {
-        if (p.o.Zh) {
+        if (OPT(Zh)) {
             for (int e = tid; e < ncol * (nG + 1); e += BLOCK) {
                 const int c = e / (nG + 1), k = e - c * (nG + 1);
                 const int64_t gh = (col0 + c) * pitchGh;
-                p.o.Zh[gh + k] = div_grav(ldg(&p.Zghalf[gh + k]) - ldg(&p.Zghalf[gh + nG]));
+                OPT(Zh)[gh + k] = div_grav(ldg(&p.Zghalf[gh + k]) - ldg(&p.Zghalf[gh + nG]));
             }
         }
     }
     STAMP(5);
+#undef OPT
 }
 
 // =================================================================================================

@@ -30,7 +30,7 @@ def short(name):
 def main():
     fdir, wdir, n_cols, copy_bytes = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
     out = sys.argv[5] if len(sys.argv) > 5 else "profiles/traffic.json"
-    res = {"n_cols": n_cols, "copy_bytes": copy_bytes, "units": "rocprofv3 FETCH_SIZE / WRITE_SIZE are KiB", "kernels": {}}
+    res = {"n_cols": n_cols, "copy_bytes": copy_bytes, "tag": os.environ.get("PMC_TAG", "round 2"), "units": "rocprofv3 FETCH_SIZE / WRITE_SIZE are KiB", "kernels": {}}
     for counter, d in (("FETCH_SIZE", fdir), ("WRITE_SIZE", wdir)):
         for name, vals in collect(d, counter).items():
             k = short(name)
@@ -44,10 +44,11 @@ def main():
         if k in ks and "FETCH_SIZE_KiB_avg" in ks[k]:
             ks[k]["fetch_counter_over_true"] = ks[k]["FETCH_SIZE_KiB_avg"] * 1024 / copy_bytes
             ks[k]["write_counter_over_true"] = ks[k].get("WRITE_SIZE_KiB_avg", 0) * 1024 / copy_bytes
-    cal = ks.get("k_copy8", {})
-    fr, wr = cal.get("fetch_counter_over_true", 0.5), cal.get("write_counter_over_true", 1.0)
-    res["calibration"] = {"pattern": "8 B/lane coalesced (k_copy8)", "fetch_counter_over_true": fr, "write_counter_over_true": wr}
-    for k in ("k_forward", "k_backward"):
+    res["calibration"] = {}
+    for k, calk in (("k_forward", "k_copy16"), ("k_backward", "k_copy8")):    # K1 (16 B/lane at config 3), K3 (8 B/lane)
+        cal = ks.get(calk, {})
+        fr, wr = cal.get("fetch_counter_over_true", 0.5), cal.get("write_counter_over_true", 1.0)
+        res["calibration"][k] = {"pattern": calk, "fetch_counter_over_true": fr, "write_counter_over_true": wr}
         if k in ks:
             f = ks[k].get("FETCH_SIZE_KiB_avg", 0) * 1024 / (fr or 1)
             w = ks[k].get("WRITE_SIZE_KiB_avg", 0) * 1024 / (wr or 1)

@@ -44,6 +44,7 @@ template <typename F> __device__ __forceinline__ auto vn_leaf(const F &term, int
     T r0 = term(lo), r1 = term(lo + 1), r2 = term(lo + 2), r3 = term(lo + 3), r4 = term(lo + 4), r5 = term(lo + 5),
       r6 = term(lo + 6), r7 = term(lo + 7);
     int i = 8;
+#pragma unroll 4      // 4 x 8 terms: their loads are issued together (the sweep is load-latency bound: few waves)
     for (; i < n - (n % 8); i += 8) {
         r0 += term(lo + i); r1 += term(lo + i + 1); r2 += term(lo + i + 2); r3 += term(lo + i + 3);
         r4 += term(lo + i + 4); r5 += term(lo + i + 5); r6 += term(lo + i + 6); r7 += term(lo + i + 7);
@@ -173,6 +174,7 @@ __global__ __launch_bounds__(64) void k_vnudge(const VnP p)
         // numpy.argmax(qt - qsat) over the plane in C order: first maximum, a NaN wins
         int best = 0;
         double bv = pl.qt[0] - pl.qsat[0];
+#pragma unroll 8
         for (int ij = 1; ij < p.nij && !(bv != bv); ++ij) {
             const double v = pl.qt[(int64_t)ij * pl.stride] - pl.qsat[(int64_t)ij * pl.stride];
             if (v > bv || v != v) { bv = v; best = ij; }
@@ -191,14 +193,17 @@ __global__ __launch_bounds__(64) void k_vnudge(const VnP p)
                 a = vn_brentq<true>(pl, ql_ref, 0.0, 5.0, g0, g5, &e2);
                 err |= e2;
                 st |= VN_ADD;
-                if (!e2)
+                if (!e2) {
+#pragma unroll 16
                     for (int ij = 0; ij < p.nij; ++ij) qt[(int64_t)ij * p.ktot] += a * pl.R[ij];       // qt[:,:,k] += a*R
+                }
             } else {
                 st |= VN_ADD_SKIPPED;
             }
             beta = 1.0;
         } else {
             const double bm1 = beta - 1;                                           // spcpl.py:724-725
+#pragma unroll 16
             for (int ij = 0; ij < p.nij; ++ij) {
                 const double q = qt[(int64_t)ij * p.ktot];
                 qt[(int64_t)ij * p.ktot] = q + bm1 * (q - pl.qt_av);
@@ -208,6 +213,7 @@ __global__ __launch_bounds__(64) void k_vnudge(const VnP p)
             const double c = (-K<double>::rlv) / (K<double>::cp * spc_pow(div_pref0(p.presf[lev]), K<double>::rd / K<double>::cp));
             double *const thl = p.thl + base;
             const double *const ql = p.ql + base;
+#pragma unroll 8
             for (int ij = 0; ij < p.nij; ++ij) {
                 const double t = qt[(int64_t)ij * p.ktot] - pl.qsat[(int64_t)ij * pl.stride];
                 const double ql_target = (t >= 0.0 || t != t) ? t : 0.0;
@@ -218,9 +224,11 @@ __global__ __launch_bounds__(64) void k_vnudge(const VnP p)
     // qt.std(axis=(0, 1)) (spcpl.py:741): numpy reduces over (i, j) with k as the inner loop, i.e. plain sequential
     // sums in C order: mean = sum/N, then sum((x - mean)^2)/N, sqrt
     double s = 0.0;
+#pragma unroll 32
     for (int ij = 0; ij < p.nij; ++ij) s += qt[(int64_t)ij * p.ktot];
     const double mean = s / (double)p.nij;
     double v = 0.0;
+#pragma unroll 32
     for (int ij = 0; ij < p.nij; ++ij) {
         const double dlt = qt[(int64_t)ij * p.ktot] - mean;
         v += dlt * dlt;

@@ -271,9 +271,11 @@ class ColumnBatch:
         hn = self.buf.les_in.hn
         rows = [source(les) for les in self.les_models]
         for k in keys:
-            dst = hn[k]
-            for i, r in enumerate(rows):
-                dst[i] = _num(_result(r[k]))
+            vals = [_num(_result(r[k])) for r in rows]
+            if hn[k].ndim == 2:
+                numpy.stack(vals, out=hn[k])          # one C loop per variable, straight into pinned memory
+            else:
+                hn[k][:] = vals
         self.buf.les_in.upload()
         return {k: self.buf.les_in.d[k] for k in keys}
 

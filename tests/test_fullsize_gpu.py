@@ -73,6 +73,20 @@ def test_full_size_config(eng, cfg):
     assert numpy.abs(F["f_thl"][rows] - rf["f_thl"]).max() <= 8 * EPS * thl_scale / DT
     assert numpy.abs(F["f_thl"][rows] - rf["f_thl"]).max() <= 1e-10 * numpy.abs(rf["f_thl"]).max()   # north-star bar
 
+    # (1b) the LEAN hot-path plans (what bench.py times: at these sizes first-generation K1, 8-column second-generation
+    # K3 for config 4) against the full-output launches above, bit for bit on the WHOLE batch
+    import ctypes
+    fp, bp = eng.plan_exchange(g, zf_d, zh_d, p, 1.0, 1.0, DT)
+    sptr = ctypes.c_void_p(torch.cuda.current_stream(eng.device).cuda_stream)
+    fp.launch_raw(sptr)
+    bp.launch_raw(sptr)
+    torch.cuda.synchronize()
+    for k in ("f_u", "f_v", "f_thl", "f_qt", "f_ql", "ql_ref", "f_ps", "idx"):
+        assert torch.equal(fp.outputs[k], fwd[k]), k
+    for k in ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A"):
+        assert numpy.array_equal(host(bp.outputs[k]), B[k], equal_nan=True), k
+    del fp, bp
+
     # (2a) batch-split invariance on the whole batch (different workgroup <-> column mapping, same bits)
     h = n // 2 + 3
     for lo, hi in ((0, h), (h, n)):

@@ -1339,7 +1339,7 @@ int spc_variability_nudge_f64(const spc_vnudge_args *a, void *stream)
     p.presf = (const double *)a->presf; p.ql_ref = (const double *)a->ql_ref; p.ql = (const double *)a->ql;
     p.qt = (double *)a->qt; p.thl = (double *)a->thl; p.beta = (double *)a->beta; p.a_add = (double *)a->a_add;
     p.qt_std = (double *)a->qt_std; p.status = a->status;
-    hipLaunchKernelGGL(k_vnudge, dim3((unsigned)((a->ktot + 63) / 64), (unsigned)a->n_cols), dim3(64), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(k_vnudge, dim3((unsigned)((a->ktot + VN_KT - 1) / VN_KT), (unsigned)a->n_cols), dim3(64 * VN_WAVES), 0, (hipStream_t)stream, p);
     return launch_status("k_vnudge");
 }
 

@@ -1033,8 +1033,8 @@ V2Choice v2_pick(const char *env, int pass, int64_t n_cols, int nG, int nL)
     if (env_pair(env, &c.cb, &c.block)) return c;
     c.cb = 0; c.block = 0;
     if (nG == 91 && nL == 160) {
-        if (pass == 0 && n_cols >= 6000 && n_cols <= 100000) c = V2Choice{2, 192};
-        if (pass == 1 && n_cols >= 200000) c = V2Choice{8, 512};
+        if (pass == 0 && n_cols >= 6000 && n_cols <= 100000) { c.cb = 2; c.block = 192; }
+        if (pass == 1 && n_cols >= 200000) { c.cb = 8; c.block = 512; }
     }
     return c;
 }

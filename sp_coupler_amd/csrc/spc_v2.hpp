@@ -97,130 +97,155 @@ __global__ __launch_bounds__(BLOCK) void k_forward_v2(const FwdP<double, false> 
     constexpr int RS = 6;
     const DimsP &d = p.d;
     const int tid = threadIdx.x;
-    const int64_t col0 = (int64_t)slab_index(d.xcd_remap) * CB;
-    const int ncol = (int)((d.n_cols - col0) < CB ? (d.n_cols - col0) : CB);
-    const int lim1 = ncol * NG, lim2 = ncol * NL;
     double *const lrec = reinterpret_cast<double *>(spc_smem);
     double *const lzf = lrec + (size_t)CB * NG * RS;
     double *const lzh = lzf + (size_t)CB * NG;
-    const int64_t g0 = col0 * NG, h0 = col0 * (NG + 1), o0 = col0 * NL;
     const bool want_idx = p.idx != nullptr;
+    const int sc = BLOCK - 1 - tid;                    // the LAST threads own the per-column scalars
 
-    // ---- load burst: everything this workgroup will ever read, issued now ------------------------------------
+    struct Slab {
+        int64_t col0, g0, h0, o0;
+        int ncol, lim1, lim2;
+    };
+    auto make_slab = [&](int64_t s) {
+        Slab sb;
+        sb.col0 = s * CB;
+        sb.ncol = (int)((d.n_cols - sb.col0) < CB ? (d.n_cols - sb.col0) : CB);
+        sb.lim1 = sb.ncol * NG; sb.lim2 = sb.ncol * NL;
+        sb.g0 = sb.col0 * NG; sb.h0 = sb.col0 * (NG + 1); sb.o0 = sb.col0 * NL;
+        return sb;
+    };
+
+    // register sets: G = what the staging pass consumes, L = what the interpolation pass consumes
     d2 gT[IT1], gSH[IT1], gQL[IT1], gQI[IT1], gPf[IT1], gZg[IT1], gU[IT1], gV[IT1];
     double zs0[IT1], zs1[IT1];
-#pragma unroll
-    for (int it = 0; it < IT1; ++it) {
-        const int e = 2 * (tid + it * BLOCK);
-        gZg[it] = ld2<WT>(p.Zgfull + g0, e, lim1);
-        gPf[it] = ld2<WT>(p.Pf + g0, e, lim1);
-        gT[it] = ld2<WT>(p.Tm + g0, e, lim1);
-        gQL[it] = ld2<WT>(p.QL + g0, e, lim1);
-        gQI[it] = ld2<WT>(p.QI + g0, e, lim1);
-        gSH[it] = ld2<WT>(p.SH + g0, e, lim1);
-        gU[it] = ld2<WT>(p.U + g0, e, lim1);
-        gV[it] = ld2<WT>(p.V + g0, e, lim1);
-        const int c0 = e / NG, c1 = (e + 1) / NG;
-        zs0[it] = e < lim1 ? p.Zghalf[h0 + (int64_t)c0 * (NG + 1) + NG] : 0.0;           // spcpl.py:197-198
-        zs1[it] = e + 1 < lim1 ? p.Zghalf[h0 + (int64_t)c1 * (NG + 1) + NG] : 0.0;
-    }
     d2 lh[IT2], lu[IT2], lv[IT2], lthl[IT2], lqt[IT2], lql[IT2];
-#pragma unroll
-    for (int it = 0; it < IT2; ++it) {
-        // odd iterations run over the threads in reverse, so a short last iteration lands on the waves that got
-        // no GCM items
-        const int e = 2 * (it * BLOCK + ((it & 1) ? BLOCK - 1 - tid : tid));
-        const int l = e % NL;
-        lh[it] = d.shared_grid ? ld2<0>(p.zf, l, NL) : ld2<WT>(p.zf + o0, e, lim2);              // spcpl.py:222
-        lu[it] = ld2<WT>(p.u_d + o0, e, lim2);
-        lv[it] = ld2<WT>(p.v_d + o0, e, lim2);
-        lthl[it] = ld2<WT>(p.thl_d + o0, e, lim2);
-        lqt[it] = ld2<WT>(p.qt_d + o0, e, lim2);
-        lql[it] = ld2<WT>(p.ql_d + o0, e, lim2);
-    }
-    double xzgh[ITX], xzs[ITX];
-    if (want_idx) {
-#pragma unroll
-        for (int it = 0; it < ITX; ++it) {
-            const int e = tid + it * BLOCK, c = e / NG, m = e - c * NG;
-            const int64_t gh = h0 + (int64_t)c * (NG + 1);
-            xzgh[it] = e < lim1 ? p.Zghalf[gh + (NG - 1 - m)] : 0.0;
-            xzs[it] = e < lim1 ? p.Zghalf[gh + NG] : 0.0;
-        }
-        const int nz = d.shared_grid ? NL : lim2;                                         // LES half levels -> LDS
-        for (int e = 2 * tid; e < nz; e += 2 * BLOCK)
-            *reinterpret_cast<d2 *>(lzh + e) = d.shared_grid ? ld2<0>(p.zh, e, NL) : ld2<WT>(p.zh + o0, e, lim2);
-    }
-    const int sc = BLOCK - 1 - tid;                    // the LAST threads own the per-column scalars
-    double sc_ps = 0.0, sc_psd = 0.0;
-    if (sc < ncol) {
-        sc_ps = p.Ph[h0 + (int64_t)sc * (NG + 1) + NG];                                   // spcpl.py:246
-        sc_psd = p.ps_d[col0 + sc];
-    }
+    double xzgh[ITX], xzs[ITX], sc_ps = 0.0, sc_psd = 0.0;
 
-    // ---- convert the GCM levels and stage one record per level, reversed to ascending height ------------------
+    auto issue_gcm = [&](const Slab &sb) {
 #pragma unroll
-    for (int it = 0; it < IT1; ++it) {
-        const int e0 = 2 * (tid + it * BLOCK);
+        for (int it = 0; it < IT1; ++it) {
+            const int e = 2 * (tid + it * BLOCK);
+            gZg[it] = ld2<WT>(p.Zgfull + sb.g0, e, sb.lim1);
+            gPf[it] = ld2<WT>(p.Pf + sb.g0, e, sb.lim1);
+            gT[it] = ld2<WT>(p.Tm + sb.g0, e, sb.lim1);
+            gQL[it] = ld2<WT>(p.QL + sb.g0, e, sb.lim1);
+            gQI[it] = ld2<WT>(p.QI + sb.g0, e, sb.lim1);
+            gSH[it] = ld2<WT>(p.SH + sb.g0, e, sb.lim1);
+            gU[it] = ld2<WT>(p.U + sb.g0, e, sb.lim1);
+            gV[it] = ld2<WT>(p.V + sb.g0, e, sb.lim1);
+            const int c0 = e / NG, c1 = (e + 1) / NG;
+            zs0[it] = e < sb.lim1 ? p.Zghalf[sb.h0 + (int64_t)c0 * (NG + 1) + NG] : 0.0;     // spcpl.py:197-198
+            zs1[it] = e + 1 < sb.lim1 ? p.Zghalf[sb.h0 + (int64_t)c1 * (NG + 1) + NG] : 0.0;
+        }
+    };
+    auto issue_les = [&](const Slab &sb) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int e = e0 + s;
-            if (e < lim1) {
-                const int c = e / NG, k = e - c * NG;
-                const double tt = s ? gT[it].y : gT[it].x, sh = s ? gSH[it].y : gSH[it].x, ql = s ? gQL[it].y : gQL[it].x;
-                const double qi = s ? gQI[it].y : gQI[it].x, pf = s ? gPf[it].y : gPf[it].x, zg = s ? gZg[it].y : gZg[it].x;
-                const double uu = s ? gU[it].y : gU[it].x, vv = s ? gV[it].y : gV[it].x;
-                const double zf_k = div_grav(zg - (s ? zs1[it] : zs0[it]));                // spcpl.py:198
-                const double qt_ = sh + ql + qi;                                           // spcpl.py:215
-                const double iex = spc_pow(div_pref0(pf), (-K<double>::rd) / K<double>::cp);   // sputils.py:34
-                const double thl_ = (tt - div_cp(K<double>::rlv * (ql + qi))) * iex;       // spcpl.py:214
-                const int kr = c * NG + (NG - 1 - k);                                      // [::-1], spcpl.py:224
-                d2 *const q = reinterpret_cast<d2 *>(lrec + (size_t)kr * RS);
-                q[0] = d2{thl_, qt_};
-                q[1] = d2{ql, uu};
-                q[2] = d2{vv, zf_k};
-                lzf[kr] = zf_k;
+        for (int it = 0; it < IT2; ++it) {
+            // odd iterations run over the threads in reverse, so a short last iteration lands on the waves that got
+            // no GCM items
+            const int e = 2 * (it * BLOCK + ((it & 1) ? BLOCK - 1 - tid : tid));
+            const int l = e % NL;
+            lh[it] = d.shared_grid ? ld2<0>(p.zf, l, NL) : ld2<WT>(p.zf + sb.o0, e, sb.lim2);  // spcpl.py:222
+            lu[it] = ld2<WT>(p.u_d + sb.o0, e, sb.lim2);
+            lv[it] = ld2<WT>(p.v_d + sb.o0, e, sb.lim2);
+            lthl[it] = ld2<WT>(p.thl_d + sb.o0, e, sb.lim2);
+            lqt[it] = ld2<WT>(p.qt_d + sb.o0, e, sb.lim2);
+            lql[it] = ld2<WT>(p.ql_d + sb.o0, e, sb.lim2);
+        }
+        if (want_idx) {
+#pragma unroll
+            for (int it = 0; it < ITX; ++it) {
+                const int e = tid + it * BLOCK, c = e / NG, m = e - c * NG;
+                const int64_t gh = sb.h0 + (int64_t)c * (NG + 1);
+                xzgh[it] = e < sb.lim1 ? p.Zghalf[gh + (NG - 1 - m)] : 0.0;
+                xzs[it] = e < sb.lim1 ? p.Zghalf[gh + NG] : 0.0;
             }
         }
-    }
+        if (sc < sb.ncol) {
+            sc_ps = p.Ph[sb.h0 + (int64_t)sc * (NG + 1) + NG];                                 // spcpl.py:246
+            sc_psd = p.ps_d[sb.col0 + sc];
+        }
+    };
+    // convert the GCM levels and stage one record per level, reversed to ascending height
+    auto stage = [&](const Slab &sb) {
+        if (want_idx && !d.shared_grid)                                                        // per-column LES half levels
+            for (int e = 2 * tid; e < sb.lim2; e += 2 * BLOCK) *reinterpret_cast<d2 *>(lzh + e) = ld2<WT>(p.zh + sb.o0, e, sb.lim2);
+#pragma unroll
+        for (int it = 0; it < IT1; ++it) {
+            const int e0 = 2 * (tid + it * BLOCK);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int e = e0 + s;
+                if (e < sb.lim1) {
+                    const int c = e / NG, k = e - c * NG;
+                    const double tt = s ? gT[it].y : gT[it].x, sh = s ? gSH[it].y : gSH[it].x, ql = s ? gQL[it].y : gQL[it].x;
+                    const double qi = s ? gQI[it].y : gQI[it].x, pf = s ? gPf[it].y : gPf[it].x, zg = s ? gZg[it].y : gZg[it].x;
+                    const double uu = s ? gU[it].y : gU[it].x, vv = s ? gV[it].y : gV[it].x;
+                    const double zf_k = div_grav(zg - (s ? zs1[it] : zs0[it]));                // spcpl.py:198
+                    const double qt_ = sh + ql + qi;                                           // spcpl.py:215
+                    const double iex = spc_pow(div_pref0(pf), (-K<double>::rd) / K<double>::cp);   // sputils.py:34
+                    const double thl_ = (tt - div_cp(K<double>::rlv * (ql + qi))) * iex;       // spcpl.py:214
+                    const int kr = c * NG + (NG - 1 - k);                                      // [::-1], spcpl.py:224
+                    d2 *const q = reinterpret_cast<d2 *>(lrec + (size_t)kr * RS);
+                    q[0] = d2{thl_, qt_};
+                    q[1] = d2{ql, uu};
+                    q[2] = d2{vv, zf_k};
+                    lzf[kr] = zf_k;
+                }
+            }
+        }
+    };
+    // two LES levels per thread: 5 fields each, forcings, 16-B stores; per-column scalars; fused K2
+    auto compute = [&](const Slab &sb) {
+        if (sc < sb.ncol) stg<(WT == 1 ? 1 : 0)>(&p.f_ps[sb.col0 + sc], SPC_DIV(p.factor * (sc_ps - sc_psd), p.dt));   // spcpl.py:332
+#pragma unroll
+        for (int it = 0; it < IT2; ++it) {
+            const int e = 2 * (it * BLOCK + ((it & 1) ? BLOCK - 1 - tid : tid));
+            if (e < sb.lim2) {
+                const int c = e / NL;
+                const double *const xs = lzf + (size_t)c * NG;
+                const double *const rc = lrec + (size_t)c * NG * RS;
+                double ra[5], rb[5];
+                interp_records<NG, 5, RS, 5>(xs, rc, lh[it].x, ra);                            // spcpl.py:224-228
+                interp_records<NG, 5, RS, 5>(xs, rc, lh[it].y, rb);
+                // record order: thl, qt, ql, u, v
+                const int64_t o0 = sb.o0;
+                const int lim2 = sb.lim2;
+                st2<WT>(p.f_u + o0, e, lim2, d2{SPC_DIV(p.factor * (ra[3] - lu[it].x), p.dt), SPC_DIV(p.factor * (rb[3] - lu[it].y), p.dt)});       // :328
+                st2<WT>(p.f_v + o0, e, lim2, d2{SPC_DIV(p.factor * (ra[4] - lv[it].x), p.dt), SPC_DIV(p.factor * (rb[4] - lv[it].y), p.dt)});       // :329
+                st2<WT>(p.f_thl + o0, e, lim2, d2{SPC_DIV(p.factor * (ra[0] - lthl[it].x), p.dt), SPC_DIV(p.factor * (rb[0] - lthl[it].y), p.dt)}); // :330
+                st2<WT>(p.f_qt + o0, e, lim2, d2{SPC_DIV(p.factor * (ra[1] - lqt[it].x), p.dt), SPC_DIV(p.factor * (rb[1] - lqt[it].y), p.dt)});    // :331
+                st2<WT>(p.f_ql + o0, e, lim2, d2{SPC_DIV(p.factor * (ra[2] - lql[it].x), p.dt), SPC_DIV(p.factor * (rb[2] - lql[it].y), p.dt)});    // :333
+                st2<WT>(p.ql_ref + o0, e, lim2, d2{ra[2], rb[2]});                                                                   // :347-348
+            }
+        }
+        if (want_idx) {                                                                        // spcpl.py:764
+#pragma unroll
+            for (int it = 0; it < ITX; ++it) {
+                const int e = tid + it * BLOCK;
+                if (e < sb.lim1) {
+                    const int c = e / NG;
+                    const double Zh_k = div_grav(xzgh[it] - xzs[it]);                          // spcpl.py:197
+                    const double *const zh = d.shared_grid ? lzh : lzh + (size_t)c * NL;
+                    p.idx[sb.g0 + e] = ss_right(zh, NL, Zh_k);
+                }
+            }
+        }
+    };
+
+    // One slab per workgroup.  (A persistent form -- each workgroup walking a contiguous run of slabs with the loads of
+    // slab s+1 re-issued into the register set the pass before had just consumed -- was built and measured in round 2:
+    // bit-correct, but 227 VGPRs -> two waves per SIMD, and 2.3x SLOWER at every size, profiles/r02_persistent_k1_ab.log;
+    // the interleaving of 4-5 resident workgroups per CU already provides that overlap.)
+    const Slab cur = make_slab((int64_t)slab_index(d.xcd_remap));
+    if (want_idx && d.shared_grid)                                                              // LES half levels -> LDS
+        for (int e = 2 * tid; e < NL; e += 2 * BLOCK) *reinterpret_cast<d2 *>(lzh + e) = ld2<0>(p.zh, e, NL);
+    issue_gcm(cur);
+    issue_les(cur);
+    stage(cur);
     __syncthreads();
-
-    if (sc < ncol) stg<(WT == 1 ? 1 : 0)>(&p.f_ps[col0 + sc], SPC_DIV(p.factor * (sc_ps - sc_psd), p.dt));       // spcpl.py:332
-
-    // ---- two LES levels per thread: 5 fields each, forcings, 16-B stores --------------------------------------
-#pragma unroll
-    for (int it = 0; it < IT2; ++it) {
-        const int e = 2 * (it * BLOCK + ((it & 1) ? BLOCK - 1 - tid : tid));
-        if (e < lim2) {
-            const int c = e / NL;
-            const double *const xs = lzf + (size_t)c * NG;
-            const double *const rc = lrec + (size_t)c * NG * RS;
-            double ra[5], rb[5];
-            interp_records<NG, 5, RS, 5>(xs, rc, lh[it].x, ra);                            // spcpl.py:224-228
-            interp_records<NG, 5, RS, 5>(xs, rc, lh[it].y, rb);
-            // record order: thl, qt, ql, u, v
-            st2<WT>(p.f_u + o0, e, lim2, d2{SPC_DIV(p.factor * (ra[3] - lu[it].x), p.dt), SPC_DIV(p.factor * (rb[3] - lu[it].y), p.dt)});       // :328
-            st2<WT>(p.f_v + o0, e, lim2, d2{SPC_DIV(p.factor * (ra[4] - lv[it].x), p.dt), SPC_DIV(p.factor * (rb[4] - lv[it].y), p.dt)});       // :329
-            st2<WT>(p.f_thl + o0, e, lim2, d2{SPC_DIV(p.factor * (ra[0] - lthl[it].x), p.dt), SPC_DIV(p.factor * (rb[0] - lthl[it].y), p.dt)}); // :330
-            st2<WT>(p.f_qt + o0, e, lim2, d2{SPC_DIV(p.factor * (ra[1] - lqt[it].x), p.dt), SPC_DIV(p.factor * (rb[1] - lqt[it].y), p.dt)});    // :331
-            st2<WT>(p.f_ql + o0, e, lim2, d2{SPC_DIV(p.factor * (ra[2] - lql[it].x), p.dt), SPC_DIV(p.factor * (rb[2] - lql[it].y), p.dt)});    // :333
-            st2<WT>(p.ql_ref + o0, e, lim2, d2{ra[2], rb[2]});                                                                   // :347-348
-        }
-    }
-
-    // ---- fused K2: cloud-fraction level-index map (spcpl.py:764) ----------------------------------------------
-    if (want_idx) {
-#pragma unroll
-        for (int it = 0; it < ITX; ++it) {
-            const int e = tid + it * BLOCK;
-            if (e < lim1) {
-                const int c = e / NG;
-                const double Zh_k = div_grav(xzgh[it] - xzs[it]);                          // spcpl.py:197
-                const double *const zh = d.shared_grid ? lzh : lzh + (size_t)c * NL;
-                p.idx[g0 + e] = ss_right(zh, NL, Zh_k);
-            }
-        }
-    }
+    compute(cur);
 }
 
 // =================================================================================================

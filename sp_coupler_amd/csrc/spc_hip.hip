@@ -885,7 +885,7 @@ void lds_elems(const spc_dims *d, int pass, bool with_idx, size_t *per_col, size
     switch (pass) {
     case 0: *per_col = 6 * nG + ((with_idx && !sh) ? nL : 0); *fixed = (with_idx && sh) ? nL : 0; break;
     case 1: *per_col = 6 * nL + nG + (sh ? 0 : nL); *fixed = sh ? nL : 0; break;
-    case 4: *per_col = 7 * (nL + 1) + 9 * nG + 1 + (sh ? 0 : 2 * nL); *fixed = sh ? 2 * nL : 0; break;
+    case 4: *per_col = 7 * (nL + 1) + 13 * nG + 1 + (sh ? 0 : 2 * nL); *fixed = sh ? 2 * nL : 0; break;
     case 2: *per_col = sh ? 0 : nL; *fixed = sh ? nL : 0; break;
     default: *per_col = 2 * nG; *fixed = 0; break;
     }
@@ -1212,12 +1212,13 @@ template <typename T> int backward_impl(const spc_dims *d, const spc_backward_ar
     static const KB kb[2][4] = {
         {k_backward<T, 0, 0, 0>, k_backward<T, 91, 160, 0>, k_backward<T, 137, 512, 0>, k_backward<T, 19, 160, 0>},
         {k_backward<T, 0, 0, 1>, k_backward<T, 91, 160, 1>, k_backward<T, 137, 512, 1>, k_backward<T, 19, 160, 1>}};
-    const int cb = cons ? pick_cb(d, 4, false, sizeof(T), k_backward_cons2<T>) : pick_cb(d, 1, false, sizeof(T), kb[0][geo]);
+    static const KB kc[4] = {k_backward_cons2<T, 0, 0>, k_backward_cons2<T, 91, 160>, k_backward_cons2<T, 137, 512>, k_backward_cons2<T, 19, 160>};
+    const int cb = cons ? pick_cb(d, 4, false, sizeof(T), kc[geo]) : pick_cb(d, 1, false, sizeof(T), kb[0][geo]);
     const int wt = small_batch(d->n_cols * (int64_t)(7 * d->nG * sizeof(T)));
     size_t per_col, fixed;
     lds_elems(d, cons ? 4 : 1, false, &per_col, &fixed);
     const size_t smem = (per_col * cb + fixed) * sizeof(T);
-    if ((rc = cons ? ensure_lds(k_backward_cons2<T>, smem, "backward (conservative)") : ensure_lds(kb[wt][geo], smem, "backward"))) return rc;
+    if ((rc = cons ? ensure_lds(kc[geo], smem, "backward (conservative)") : ensure_lds(kb[wt][geo], smem, "backward"))) return rc;
     BwdP<T> p;
     p.d = make_dims(d, cb);
     p.Tm = (const T *)a->T; CP(SH); CP(QL); CP(QI); CP(U); CP(V); CP(A); CP(Zf); CP(Zgfull); CP(Zghalf); CP(zf);
@@ -1235,7 +1236,7 @@ template <typename T> int backward_impl(const spc_dims *d, const spc_backward_ar
     }
     const unsigned grid = (unsigned)((d->n_cols + cb - 1) / cb);
     if (cons)
-        hipLaunchKernelGGL(k_backward_cons2<T>, dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(kc[geo], dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(kb[wt][geo], dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
     return launch_status(cons ? "k_backward_cons" : "k_backward");
@@ -1365,7 +1366,7 @@ int spc_pick_cols_per_block(const spc_dims *d, int pass)
     case 1: return pick_cb(d, 1, false, sizeof(double), k_backward<double, 0, 0, 0>);
     case 2: return pick_cb(d, 2, true, sizeof(double), k_cloud_idx<double>);
     case 3: return pick_cb(d, 3, false, sizeof(double), k_diag<double>);
-    case 4: return pick_cb(d, 4, false, sizeof(double), k_backward_cons2<double>);
+    case 4: return pick_cb(d, 4, false, sizeof(double), k_backward_cons2<double, 0, 0>);
     default: return fail(SPC_ERR_INVALID_ARGUMENT, "%spass must be 0..4");
     }
 }

@@ -8,16 +8,19 @@
 // accumulators, 8192-element chunks), so any nL is supported and results stay bit-identical to the NumPy
 // evaluation.  LDS per column: q[7][nL+1] = t | qt | ql | ql_ice | u | v | rho (one element of padding per
 // field: a field stride of nL x 8 B = 0 mod 64 banks would put the eight lanes of a level on one bank), then
-// Zf[nG] | Zh[nG+1] | X[7][nG] (layer means); then zf and zh ([nL] each when shared, else [CB x nL] each).
+// Zf[nG] | Zh[nG+1] | X[7][nG] (layer means) | cell range ia, ib and edge pieces da, db per level [4][nG]; then zf and zh ([nL] each when shared, else [CB x nL] each).
 #pragma once
 
-template <typename T> __global__ __launch_bounds__(BLOCK) void k_backward_cons2(const BwdP<T> p)
+// NG / NL != 0: level counts fixed at compile time and contiguous columns (as k_forward / k_backward): the flat-index
+// divisions become multiply-shifts.
+template <typename T, int NG = 0, int NL = 0> __global__ __launch_bounds__(BLOCK) void k_backward_cons2(const BwdP<T> p)
 {
     const DimsP &d = p.d;
-    const int nG = d.nG, nL = d.nL, cb = d.cb, tid = threadIdx.x, nLp = nL + 1;
+    const int nG = NG ? NG : d.nG, nL = NL ? NL : d.nL, cb = d.cb, tid = threadIdx.x, nLp = nL + 1;
+    const int64_t pitchG = NG ? NG : d.pitchG, pitchGh = NG ? NG + 1 : d.pitchGh, pitchL = NL ? NL : d.pitchL;
     const int64_t col0 = (int64_t)slab_index(d.xcd_remap) * cb;
     const int ncol = (int)((d.n_cols - col0) < cb ? (d.n_cols - col0) : cb);
-    const size_t per_col = (size_t)7 * nLp + nG + (nG + 1) + (size_t)7 * nG;
+    const size_t per_col = (size_t)7 * nLp + nG + (nG + 1) + (size_t)7 * nG + (size_t)4 * nG;   // + cell ranges / edge pieces per level
     T *const lds = reinterpret_cast<T *>(spc_smem);
     T *const lh = lds + (size_t)cb * per_col;                    // zf
     T *const lzh = lh + (d.shared_grid ? nL : (size_t)cb * nL);  // zh
@@ -26,7 +29,7 @@ template <typename T> __global__ __launch_bounds__(BLOCK) void k_backward_cons2(
     // ---- stage the LES slab, the LES grids and the GCM heights ------------------------------------------------
     for (int e = tid; e < ncol * nL; e += BLOCK) {
         const int c = e / nL, l = e - c * nL;
-        const int64_t o = (col0 + c) * d.pitchL + l;
+        const int64_t o = (col0 + c) * pitchL + l;
         T *const s = lds + (size_t)c * per_col + l;
         s[0] = p.t_d[o];
         s[nLp] = p.qt_d[o];
@@ -41,13 +44,44 @@ template <typename T> __global__ __launch_bounds__(BLOCK) void k_backward_cons2(
         for (int e = tid; e < nL; e += BLOCK) { lh[e] = p.zf[e]; lzh[e] = p.zh[e]; }
     for (int e = tid; e < ncol * (nG + 1); e += BLOCK) {
         const int c = e / (nG + 1), k = e - c * (nG + 1);
-        const int64_t col = col0 + c, gh = col * d.pitchGh;
+        const int64_t col = col0 + c, gh = col * pitchGh;
         T *const s = lds + (size_t)c * per_col + 7 * nLp;
         s[nG + k] = p.Zh ? p.Zh[gh + k] : div_grav(p.Zghalf[gh + k] - p.Zghalf[gh + nG]);      // spcpl.py:197
         if (k < nG) {
-            const int64_t g = col * d.pitchG + k;
+            const int64_t g = col * pitchG + k;
             s[k] = p.Zf ? p.Zf[g] : div_grav(p.Zgfull[g] - p.Zghalf[gh + nG]);                  // spcpl.py:198
         }
+    }
+    __syncthreads();
+
+    // ---- per GCM level, once: which LES cells the layer [Zh[k+1], Zh[k]] covers (the scans of integral(), sputils.py:
+    //      113-127).  ia < 0 encodes the two special outcomes: -1 layer above the LES top (Q stays 0, sputils.py:187),
+    //      -2 an end point outside zh (integral returns None -> NaN).
+    for (int e = tid; e < n1; e += BLOCK) {
+        const int c = e / nG, k = e - c * nG;
+        T *const s = lds + (size_t)c * per_col;
+        const T *const z = d.shared_grid ? lzh : lzh + (size_t)c * nL;
+        const T *const Zh = s + 7 * nLp + nG;
+        int *const cell = reinterpret_cast<int *>(s + 7 * nLp + nG + (nG + 1) + (size_t)7 * nG);      // ia[nG] | ib[nG] (ints in 2 nG elements)
+        T *const edge = s + 7 * nLp + nG + (nG + 1) + (size_t)7 * nG + 2 * nG;                        // da[nG] | db[nG]
+        int ia = -1, ib = -1;
+        T da = T(0), db = T(0);
+        if (Zh[k] < z[nL - 1]) {                                                       // sputils.py:187
+            T a = Zh[k + 1], b = Zh[k];                                                // integral(ZZ[i+1], ZZ[i], ...)
+            if (a < z[0] || a > z[nL - 1] || b < z[0] || b > z[nL - 1]) {
+                ia = -2;                                                               // sputils.py:113-115
+            } else {
+                const bool swap = a > b;                                               // sputils.py:117-120
+                if (swap) { const T t = a; a = b; b = t; }
+                ia = scan_cell(z, nL, a);                                              // sputils.py:122-124
+                ib = scan_cell(z, nL, b);                                              // sputils.py:125-127
+                if (ib < ia) ib = ia;
+                da = a - z[ia]; db = z[ib + 1] - b;
+                if (swap) ib = -ib - 2;                                                // sign = -1 encoded in ib < 0
+            }
+        }
+        cell[k] = ia; cell[nG + k] = ib;
+        edge[k] = da; edge[nG + k] = db;
     }
     __syncthreads();
 
@@ -56,36 +90,34 @@ template <typename T> __global__ __launch_bounds__(BLOCK) void k_backward_cons2(
         const int f = e & 7, ck = e >> 3, c = ck / nG, k = ck - c * nG;
         T *const s = lds + (size_t)c * per_col;
         const T *const z = d.shared_grid ? lzh : lzh + (size_t)c * nL;
-        const T *const Zh = s + 7 * nLp + nG, *const w = s + 6 * nLp;
+        const T *const w = s + 6 * nLp;
+        const int *const cell = reinterpret_cast<const int *>(s + 7 * nLp + nG + (nG + 1) + (size_t)7 * nG);
+        const T *const edge = s + 7 * nLp + nG + (nG + 1) + (size_t)7 * nG + 2 * nG;
+        const int ia = cell[k];
         T X = T(0);                                                                    // Q = zeros (sputils.py:185)
-        if (Zh[k] < z[nL - 1]) {                                                       // sputils.py:187
-            T a = Zh[k + 1], b = Zh[k];                                                // integral(ZZ[i+1], ZZ[i], ...)
-            if (a < z[0] || a > z[nL - 1] || b < z[0] || b > z[nL - 1]) {
-                X = T(0) / T(0);       // sputils.py:113-115 returns None; Q[i] = None stores NaN (numpy 2.x)
-            } else {
-                T sign = T(1);
-                if (a > b) { sign = T(-1); const T t = a; a = b; b = t; }              // sputils.py:117-120
-                const int ia = scan_cell(z, nL, a);                                    // sputils.py:122-124
-                int ib = scan_cell(z, nL, b);                                          // sputils.py:125-127
-                if (ib < ia) ib = ia;
-                const int cnt = ib - ia + 1;
-                const T da = a - z[ia], db = z[ib + 1] - b;
-                // fields in the order of spcpl.py:482-488: t, qt, ql, ql_water (= ql - ql_ice, :402), ql_ice, u, v
-                const T *const qa = s + (size_t)(f < 3 ? f : (f < 7 ? f - 1 : 0)) * nLp;
-                const T *const qb = s + (size_t)3 * nLp;
-                const bool sub = (f == 3), wsum = (f == 7);
-                auto q = [&](int i) { return sub ? qa[i] - qb[i] : qa[i]; };
-                auto term = [&](int i) {
-                    const T dz = z[ia + i + 1] - z[ia + i];
-                    return wsum ? w[ia + i] * dz : (w[ia + i] * q(ia + i)) * dz;       // sputils.py:152 / 157
-                };
-                const T S = cnt <= 128 ? T(0) + vn_leaf(term, 0, cnt) : vn_npsum(term, cnt);
-                const T ea = wsum ? w[ia] * da : (w[ia] * q(ia)) * da;                 // Sa / Swa, sputils.py:154,159
-                const T eb = wsum ? w[ib] * db : (w[ib] * q(ib)) * db;                 // Sb / Swb
-                const T num = (S - ea) - eb;
-                const T den = __shfl(num, (threadIdx.x & 63) | 7);                     // the level's weight lane
-                X = num / den * sign;                                                  // sputils.py:161
-            }
+        if (ia == -2) {
+            X = T(0) / T(0);           // Q[i] = None stores NaN (numpy 2.x)
+        } else if (ia >= 0) {
+            int ib = cell[nG + k];
+            T sign = T(1);
+            if (ib < 0) { ib = -ib - 2; sign = T(-1); }
+            const int cnt = ib - ia + 1;
+            const T da = edge[k], db = edge[nG + k];
+            // fields in the order of spcpl.py:482-488: t, qt, ql, ql_water (= ql - ql_ice, :402), ql_ice, u, v
+            const T *const qa = s + (size_t)(f < 3 ? f : (f < 7 ? f - 1 : 0)) * nLp;
+            const T *const qb = s + (size_t)3 * nLp;
+            const bool sub = (f == 3), wsum = (f == 7);
+            auto q = [&](int i) { return sub ? qa[i] - qb[i] : qa[i]; };
+            auto term = [&](int i) {
+                const T dz = z[ia + i + 1] - z[ia + i];
+                return wsum ? w[ia + i] * dz : (w[ia + i] * q(ia + i)) * dz;           // sputils.py:152 / 157
+            };
+            const T S = cnt <= 128 ? T(0) + vn_leaf(term, 0, cnt) : vn_npsum(term, cnt);
+            const T ea = wsum ? w[ia] * da : (w[ia] * q(ia)) * da;                     // Sa / Swa, sputils.py:154,159
+            const T eb = wsum ? w[ib] * db : (w[ib] * q(ib)) * db;                     // Sb / Swb
+            const T num = (S - ea) - eb;
+            const T den = __shfl(num, (threadIdx.x & 63) | 7);                         // the level's weight lane
+            X = num / den * sign;                                                      // sputils.py:161
         }
         if (f < 7) s[7 * nLp + nG + (nG + 1) + (size_t)f * nG + k] = X;
     }
@@ -94,7 +126,7 @@ template <typename T> __global__ __launch_bounds__(BLOCK) void k_backward_cons2(
     // ---- tendencies: flat over the [ncol x nG] slab, as K3 (spcpl.py:498, 518-533) -----------------------------
     for (int e = tid; e < n1; e += BLOCK) {
         const int c = e / nG, k = e - c * nG;
-        const int64_t col = col0 + c, cg = col * d.pitchG, g = cg + k;
+        const int64_t col = col0 + c, cg = col * pitchG, g = cg + k;
         const T *const s = lds + (size_t)c * per_col;
         const T *const h = d.shared_grid ? lh : lh + (size_t)c * nL;
         const T *const Zf = s + 7 * nLp, *const X = Zf + nG + (nG + 1);

@@ -463,3 +463,49 @@ def test_second_generation_kernels_every_variant_ragged_tails_and_edges(eng, nG,
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_second_generation_kernels_random_batch_sizes(eng):
+    """Soak of the compile-time-geometry kernels: random column counts (ragged last slabs of every parity), random
+    variant, shared / per-column LES grid, forced on through SPC_V2_K1 / SPC_V2_K3 -- each launch bit-checked against
+    the plain-C oracle.  SPC_FUZZ_TRIALS / SPC_FUZZ_SEED scale it (default 24 trials)."""
+    import ctypes
+    import os
+    rng = numpy.random.default_rng(int(os.environ.get("SPC_FUZZ_SEED", "2026")) + 1)
+    sptr = ctypes.c_void_p(torch.cuda.current_stream(eng.device).cuda_stream)
+    saved = {k: os.environ.get(k) for k in ("SPC_V2_K1", "SPC_V2_K3", "SPC_V2_REMAP", "SPC_V2_NT")}
+    try:
+        for trial in range(max(6, int(os.environ.get("SPC_FUZZ_TRIALS", "24")))):
+            nG, nL = [(91, 160), (137, 512), (19, 160)][int(rng.integers(0, 3))]
+            n = int(rng.integers(1, 2200 if nL == 160 else 500))
+            per_col = bool(rng.integers(0, 2))
+            os.environ["SPC_V2_K1"] = str(rng.choice(V2_VARIANTS[(nG, nL)]))
+            os.environ["SPC_V2_K3"] = str(rng.choice(V2_VARIANTS[(nG, nL)]))
+            os.environ["SPC_V2_REMAP"] = str(int(rng.integers(0, 2)))
+            os.environ["SPC_V2_NT"] = str(int(rng.integers(0, 2)))
+            gcm, zf, zh, prof = synthetic.make_batch(n, nG, nL, seed=9100 + trial, per_column_grid=per_col, couple_surface=False)
+            g, p = to_dev(gcm, eng.device), to_dev(prof, eng.device)
+            zf_d, zh_d = torch.from_numpy(zf).to(eng.device), torch.from_numpy(zh).to(eng.device)
+            fp, bp = eng.plan_exchange(g, zf_d, zh_d, p, FACTOR, FACTOR, DT)
+            for pl in (fp, bp):
+                for t in pl.outputs.values():
+                    t.fill_(float("nan")) if t.is_floating_point() else t.fill_(-7)
+                pl.launch_raw(sptr)
+            torch.cuda.synchronize()
+            ref_f = oracle_c.forward(gcm, zf, zh, prof, FACTOR, DT, couple_surface=False)
+            ref_b = oracle_c.backward(gcm, None, zf, prof, FACTOR, DT)
+            tag = "trial %d %d<->%d n=%d per_col=%s K1=%s K3=%s: " % (trial, nG, nL, n, per_col, os.environ["SPC_V2_K1"],
+                                                                       os.environ["SPC_V2_K3"])
+            F = {k: host(v) for k, v in fp.outputs.items()}
+            assert_bits(tag + "idx", F["idx"], ref_f["idx"])
+            for k in ("f_u", "f_v", "f_qt", "f_ql", "ql_ref", "f_ps"):
+                assert_bits(tag + k, F[k], ref_f[k])
+            assert_close_scaled(tag + "f_thl", F["f_thl"], ref_f["f_thl"], 8 * EPS, numpy.abs(ref_f["thl"]).max() * abs(FACTOR) / DT)
+            for k in ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A"):
+                assert_bits(tag + k, host(bp.outputs[k]), ref_b[k])
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

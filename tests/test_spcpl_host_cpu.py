@@ -223,3 +223,31 @@ def test_batched_model_protocol_equals_the_per_les_path(tmp_path, cplsurf, conse
         assert numpy.isfinite(cb["f_T"]).all() and numpy.isfinite(cb["rainrate"]).all()
     # the per-column faces of an ensemble speak the reference's per-LES protocol too
     assert ens[2].get_profile_U().shape == (160,) and ens[2].grid_index == les_a[2].grid_index
+
+
+def test_spinup_with_an_ensemble_equals_the_per_les_spinup(tmp_path):
+    """step_spinup (splib/splib.py:355-402) through the batched protocol: same LES state and same spifs rows as the
+    per-LES calls."""
+    from sp_coupler_amd import spio
+    from sp_coupler_amd.driver import Coupler
+    gcm_a, les_a = models.make_models(4, nG=19, nL=160, seed=12)
+    gcm_b, les_b = models.make_models(4, nG=19, nL=160, seed=12)
+    gcm_b.__class__ = models.BatchedSyntheticGCM
+    ens = models.SyntheticLESEnsemble.from_models(les_b)
+    out = []
+    for tag, gcm, les in (("a", gcm_a, les_a), ("b", gcm_b, ens)):
+        path = str(tmp_path / ("spin_%s.nc" % tag))
+        spcpl.writer = spio.SpifsWriter(path, [m.grid_index for m in les_a], [0] * 4, [0] * 4, les_a[0].zf_cache, 19)
+        cpl = Coupler(gcm, les, write=True)
+        for s_ in range(2):
+            spcpl.writer.update_time(100.0 * (s_ + 1))
+            cpl.step_spinup(100.0, les_spinup_forcing_factor=0.5)
+        spcpl.writer.close()
+        spcpl.writer = None
+        out.append(spio.read_column(path, 2))
+    for i, m in enumerate(les_a):
+        for k in ("U", "THL", "QT", "T"):
+            assert numpy.array_equal(numpy.asarray(m.p[k]), ens.p[k][i]), (k, i)
+    assert ens.model_time == les_a[0].model_time == 200.0
+    for k in out[0]:
+        assert numpy.array_equal(out[0][k], out[1][k], equal_nan=True), k

@@ -181,3 +181,55 @@ def test_no_sign_change_for_the_additive_noise_raises_like_scipy():
     numpy.random.seed(1)
     r = vo.variability_nudge(f["qt"], f["qsat"], f["ql_av"], f["qt_av"], f["presf"], f["ql_ref"], vo.make_R(8, 8), 900.0)
     assert isinstance(r["error"], ValueError)
+
+
+@pytest.mark.gpu
+def test_variance_forcing_through_set_les_forcings_like_splib_step():
+    """qt_forcing='variance' through the drop-in call the reference's step makes (splib/splib.py:320 ->
+    spcpl.py:377-382): after the forcings of a step, every LES whose model time is > 0 gets its 3-D qt nudged toward
+    the GCM's ql profile interpolated to LES levels (les.ql_ref, K1's output) -- compared with the oracle fed the same
+    ql_ref; an LES still at model time 0 is left alone; R is drawn from numpy's global generator in les order."""
+    from sp_coupler_amd import models, spcpl
+    spcpl.set_engine(None)
+
+    class FieldSyntheticLES(models.SyntheticLES):
+        def attach_fields(self, seed):
+            f = make_les_fields(8, 8, self.nL, seed)
+            self.f3 = f
+            self.fields = FieldLES._Fields()
+
+        def get_itot(self):
+            return 8
+
+        def get_jtot(self):
+            return 8
+
+        def get_field(self, name):
+            return {"Qsat": self.f3["qsat"], "QT": self.f3["qt"], "THL": self.f3["thl"], "QL": self.f3["ql"]}[name].copy()
+
+        def get_profile(self, name):
+            return {"QL": self.f3["ql_av"], "QT": self.f3["qt_av"]}[name].copy()
+
+    gcm = models.SyntheticGCM(8, 91, seed=4)
+    les_models = []
+    for i in (1, 2, 3):
+        les = FieldSyntheticLES(gcm, i, 160, seed=4)
+        les.zf_cache, les.zh_cache = les.get_zf(), les.get_zh()
+        les.attach_fields(seed=40 + i)
+        les_models.append(les)
+    les_models[0].model_time = les_models[1].model_time = 900.0        # the third LES has not been stepped yet
+    spcpl.gather_gcm_data(gcm, les_models, False, write=False)
+    numpy.random.seed(7)
+    reqs = spcpl.set_les_forcings_batched(les_models, gcm, True, True, {}, dt_gcm=900.0, factor=1.0, couple_surface=False,
+                                          qt_forcing='variance', write=False, variability_nudge_constant_T=True)
+    assert len(reqs) == 3 and set(reqs[0]) == {"U", "V", "THL", "QT", "SP", "QL", "QLp"}
+    assert not hasattr(les_models[2].fields, "QT")                                   # model time 0: no nudge
+    numpy.random.seed(7)
+    for les in les_models[:2]:
+        f = les.f3
+        r = vo.variability_nudge(f["qt"], f["qsat"], f["ql_av"], f["qt_av"], f["presf"], numpy.asarray(les.ql_ref),
+                                 vo.make_R(8, 8), 900.0, True, thl=f["thl"], ql=f["ql"])
+        assert r["error"] is None
+        assert numpy.array_equal(les.fields.QT, r["qt"])
+        assert numpy.abs(les.fields.THL - r["thl"]).max() <= 8 * 2.220446049250313e-16 * numpy.abs(r["thl"]).max()
+        assert (r["status"] != 0).any()

@@ -227,7 +227,7 @@ def test_variance_forcing_through_set_les_forcings_like_splib_step():
     numpy.random.seed(7)
     for les in les_models[:2]:
         f = les.f3
-        r = vo.variability_nudge(f["qt"], f["qsat"], f["ql_av"], f["qt_av"], f["presf"], numpy.asarray(les.ql_ref),
+        r = vo.variability_nudge(f["qt"], f["qsat"], f["ql_av"], f["qt_av"], les.get_presf(), numpy.asarray(les.ql_ref),
                                  vo.make_R(8, 8), 900.0, True, thl=f["thl"], ql=f["ql"])
         assert r["error"] is None
         assert numpy.array_equal(les.fields.QT, r["qt"])

@@ -233,3 +233,40 @@ def test_variance_forcing_through_set_les_forcings_like_splib_step():
         assert numpy.array_equal(les.fields.QT, r["qt"])
         assert numpy.abs(les.fields.THL - r["thl"]).max() <= 8 * 2.220446049250313e-16 * numpy.abs(r["thl"]).max()
         assert (r["status"] != 0).any()
+
+
+def _load_vnudge_golden():
+    import os
+    z = numpy.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vnudge_small.npz"))   # no pickle
+    return z, {k[3:]: z[k] for k in z.files if k.startswith("in_")}
+
+
+@pytest.mark.parametrize("constantT", [False, True])
+def test_oracle_reproduces_the_vnudge_golden(constantT):
+    """tests/golden/vnudge_small.npz (oracle-generated, see make_vnudge_golden.py): the oracle, numpy's sum order,
+    numpy's global generator and scipy's brentq still give the committed numbers."""
+    z, f = _load_vnudge_golden()
+    numpy.random.seed(42)
+    assert numpy.array_equal(vo.make_R(12, 10), f["R"])
+    r = vo.variability_nudge(f["qt"], f["qsat"], f["ql_av"], f["qt_av"], f["presf"], f["ql_ref"], f["R"], 900.0, constantT,
+                             thl=f["thl"], ql=f["ql"])
+    tag = "cT%d_" % int(constantT)
+    for k in ("qt", "thl", "beta", "alpha", "qt_std", "a", "status"):
+        assert numpy.array_equal(r[k], z[tag + k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("constantT", [False, True])
+def test_kernel_reproduces_the_vnudge_golden(constantT):
+    from sp_coupler_amd import spcpl
+    spcpl.set_engine(None)
+    z, f = _load_vnudge_golden()
+    les = FieldLES(f, f["ql_ref"].copy())
+    numpy.random.seed(42)
+    g = spcpl.variability_nudge(les, 900.0, constantT, write=False)
+    tag = "cT%d_" % int(constantT)
+    for k in ("beta", "alpha", "qt_std", "a", "status"):
+        assert numpy.array_equal(g[k], z[tag + k]), k
+    assert numpy.array_equal(les.fields.QT, z[tag + "qt"])
+    if constantT:
+        assert numpy.abs(les.fields.THL - z[tag + "thl"]).max() <= 8 * 2.220446049250313e-16 * numpy.abs(z[tag + "thl"]).max()

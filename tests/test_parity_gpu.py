@@ -509,3 +509,28 @@ def test_second_generation_kernels_random_batch_sizes(eng):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_exner_power_accuracy_and_special_values(eng):
+    """spc_pow, the specialised x**(-rd/cp) of iexner (sputils.py:33-34), through K5's THL = T * iexner(Pf) with T = 1:
+    pressures from 1e-3 Pa to 2e5 Pa (the atmosphere needs 1 Pa .. 1.1e5 Pa), tiny / huge normal numbers, and the
+    arguments that must take ocml's pow(): 0, subnormal, negative, inf, NaN.  Finite results within 2 ulp of numpy's
+    (libm, < 1 ulp) power; special values of the same class."""
+    rng = numpy.random.default_rng(5)
+    n, nG = 64, 91
+    pf = numpy.exp(rng.uniform(numpy.log(1e-3), numpy.log(2e5), size=(n, nG)))
+    pf[0, :8] = [1e-300, 1e300, 2.2250738585072014e-308, 1.7976931348623157e308, 1e5, 1e5 * (1 + 2 ** -52), 99999.99999999999, 3.0]
+    pf[1, :6] = [0.0, 5e-324, -1.0, numpy.inf, numpy.nan, -0.0]
+    gcm = {k: numpy.zeros((n, nG)) for k in ("SH", "QL", "QI", "Zgfull")}
+    gcm.update(T=numpy.ones((n, nG)), Pfull=pf, Zghalf=numpy.zeros((n, nG + 1)))
+    d = eng.diagnostics(to_dev(gcm, eng.device))
+    torch.cuda.synchronize()
+    got = host(d["THL"])
+    with numpy.errstate(all="ignore"):
+        want = (pf / 1e5) ** ((-287.04) / 1004.)
+    fin = numpy.isfinite(want)
+    assert numpy.array_equal(numpy.isfinite(got), fin) and numpy.array_equal(numpy.isnan(got), numpy.isnan(want))
+    assert numpy.array_equal(got[numpy.isinf(want)], want[numpy.isinf(want)])
+    ulp = numpy.abs(got[fin] - want[fin]) / numpy.spacing(numpy.abs(want[fin]))
+    assert ulp.max() <= 2.0, ulp.max()
+    assert (ulp <= 1.0).mean() > 0.999

@@ -25,7 +25,6 @@ setters are plain float64 NumPy arrays unless ``set_unit_wrapper`` installs a wr
 (INTEGRATION.md shows the OMUSE one).
 """
 import logging
-import os
 import time
 
 import numpy
@@ -88,14 +87,6 @@ def _result(x):
     return x.result() if hasattr(x, "result") and callable(x.result) else x
 
 
-_OVERLAP = os.environ.get("SPC_OVERLAP", "1") != "0"
-
-
-class _Done:
-    def synchronize(self):
-        return None
-
-
 class Arena:
     """Named arrays packed into ONE pinned host buffer and ONE device buffer, so that a whole group of inputs
     (or results) crosses PCIe in a single copy.  ``h[name]`` / ``hn[name]`` are the host views (torch / NumPy),
@@ -115,53 +106,18 @@ class Arena:
         on_gpu = self.device.type == "cuda"
         self.host = torch.empty(max(off, 1), dtype=torch.uint8, pin_memory=on_gpu)
         self.dev = torch.empty(max(off, 1), dtype=torch.uint8, device=self.device) if on_gpu else self.host
-        self.h, self.d, self.hn, self.end, self.start = {}, {}, {}, {}, {}
+        self.h, self.d, self.hn, self.end = {}, {}, {}, {}
         for name, shape, dtype, o, nb in lay:
             self.h[name] = self.host[o:o + nb].view(dtype).view(shape)
             self.d[name] = self.dev[o:o + nb].view(dtype).view(shape)
             self.hn[name] = self.h[name].numpy()
-            self.start[name], self.end[name] = o, o + nb
-        # a second stream for copies that overlap HOST work (the next getter filling the next part of the buffer, the
-        # setter consuming the part that has already arrived); SPC_OVERLAP=0 keeps every copy on the compute stream
-        self.copy_stream = torch.cuda.Stream(self.device) if (on_gpu and _OVERLAP) else None
+            self.end[name] = o + nb
 
     def upload(self, upto=None):
         """host -> device (one async copy on the current stream; later kernels on that stream are ordered after it)"""
         if self.dev is not self.host:
             n = self.nbytes if upto is None else self.end[upto]
             self.dev[:n].copy_(self.host[:n], non_blocking=True)
-
-    def upload_span(self, first, last):
-        """host -> device of the members first..last (contiguous in the buffer), asynchronously on the copy stream;
-        ``uploads_done()`` orders the compute stream behind every span issued so far"""
-        if self.dev is self.host:
-            return
-        a, b = self.start[first], self.end[last]
-        if self.copy_stream is None:
-            self.dev[a:b].copy_(self.host[a:b], non_blocking=True)
-            return
-        with torch.cuda.stream(self.copy_stream):
-            self.dev[a:b].copy_(self.host[a:b], non_blocking=True)
-
-    def uploads_done(self):
-        if self.copy_stream is not None:
-            torch.cuda.current_stream(self.device).wait_stream(self.copy_stream)
-
-    def download_span(self, first, last):
-        """device -> host of the members first..last behind everything enqueued on the compute stream so far;
-        returns an object whose ``synchronize()`` waits for just this span"""
-        if self.dev is self.host:
-            return _Done()
-        a, b = self.start[first], self.end[last]
-        cur = torch.cuda.current_stream(self.device)
-        cs = self.copy_stream or cur
-        if cs is not cur:
-            cs.wait_stream(cur)
-        with torch.cuda.stream(cs):
-            self.host[a:b].copy_(self.dev[a:b], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(cs)
-        return ev
 
     def download(self, upto=None):
         """device -> host of the arrays up to and including ``upto`` (default all), then wait for it"""
@@ -254,24 +210,20 @@ class ColumnBatch:
             nG = first.shape[1]
         self.buf = b = _get_buffers(engine, self.n, n_total, int(nG), nL, couple_surface)
         hn = b.gcm_in.hn
-        half = len(gcm_vars) // 2
-        for i, v in enumerate(gcm_vars):                                      # spcpl.py:62-67
+        for v in gcm_vars:                                                    # spcpl.py:62-67
             if v == gcm_vars[0] and first is not None:
                 numpy.copyto(hn[v], first)
             elif use_out:
                 gcm.get_profile_fields(v, cols, out=hn[v])
             else:
                 numpy.copyto(hn[v], _num(gcm.get_profile_fields(v, cols)))
-            if i == half - 1:
-                b.gcm_in.upload_span(gcm_vars[0], v)      # the first half crosses PCIe while the getters fill the second
         if couple_surface:
             for v in surf_vars:                                               # spcpl.py:69-75
                 if use_out:
                     gcm.get_surface_field(v, cols, out=hn[v])
                 else:
                     numpy.copyto(hn[v], _num(gcm.get_surface_field(v, cols)))
-        b.gcm_in.upload_span(gcm_vars[half], surf_vars[-1] if couple_surface else gcm_vars[-1])
-        b.gcm_in.uploads_done()
+        b.gcm_in.upload()
         self.gcm_host = {v: hn[v] for v in gcm_vars}      # rows n.. are the extra output columns
         self.surf_host = {v: hn[v] for v in surf_vars} if couple_surface else {}
         n = self.n
@@ -430,7 +382,7 @@ def _plan(batch, kind, flags, make):
     return plan
 
 
-def forward_batched(batch, profiles, dt_gcm, factor, couple_surface=False, download=True):
+def forward_batched(batch, profiles, dt_gcm, factor, couple_surface=False):
     """K1 (+fused K2) for every column of ``batch`` -- the LEAN hot-path kernel bench.py times (the six setter
     arrays, f_ps and the index map; with ``couple_surface`` also the surface fluxes).  ``profiles``: dict of device
     tensors U,V,THL,QT,QL [n x nL], PS [n] (views of the step's upload buffer).  Returns dict of HOST arrays: views
@@ -453,8 +405,7 @@ def forward_batched(batch, profiles, dt_gcm, factor, couple_surface=False, downl
     else:
         res = eng.forward(batch.gcm, batch.zf, prof, float(factor), dt, zh=batch.zh, want_profiles=False,
                           want_heights=False, couple_surface=couple_surface, out=out)
-    if download:
-        b.fwd_out.download(upto="wqt" if couple_surface else "idx")
+    b.fwd_out.download(upto="wqt" if couple_surface else "idx")
     host = {k: b.fwd_out.hn[k] for k in _FWD_CORE}
     if couple_surface:
         host["wthl"], host["wqt"] = b.fwd_out.hn["wthl"], b.fwd_out.hn["wqt"]
@@ -610,17 +561,12 @@ def _ensemble_forcings(ens, firststep, profiles, dt_gcm, factor, couple_surface,
         raise RuntimeError("set_les_forcings_batched: pass what get_les_profiles_batched() returned after the last "
                            "LES step (the slab means of this batch geometry are not on the device)")
     dev = b.les_in.d
-    host = forward_batched(batch, dev, dt_gcm, factor, couple_surface, download=False)
-    # the results come down in two spans; the setters of the first run while the second is still on the wire
-    ev1 = b.fwd_out.download_span("f_u", "f_thl")
-    ev2 = b.fwd_out.download_span("f_qt", "wqt" if couple_surface else "idx")
+    host = forward_batched(batch, dev, dt_gcm, factor, couple_surface)
     _finish_forward(batch, host, hn["Rain"], getattr(b, "rain_prev", numpy.zeros(batch.n)), dt_gcm)
     b.rain_prev = host["rain"]                                               # les.rain = rain, spcpl.py:324
     batch.ql_ref_host = host["ql_ref"]
-    ev1.synchronize()
-    ens.set_forcings_batched(U=host["f_u"], V=host["f_v"], THL=host["f_thl"])             # spcpl.py:341-343
-    ev2.synchronize()
-    kw = dict(QT=host["f_qt"], SP=host["f_ps"], QL=host["f_ql"], QLp=host["ql_ref"])      # spcpl.py:344-347
+    kw = dict(U=host["f_u"], V=host["f_v"], THL=host["f_thl"], QT=host["f_qt"], SP=host["f_ps"], QL=host["f_ql"],
+              QLp=host["ql_ref"])                                            # spcpl.py:341-347
     if couple_surface:                                                       # spcpl.py:359-364
         kw.update(Z0M_surf=host["z0m"], Z0H_surf=host["z0h"], WT_surf=host["wthl"], WQ_surf=host["wqt"])
     ens.set_forcings_batched(**kw)
@@ -732,14 +678,9 @@ def get_les_profiles_batched(les_models, asynchronous=False, diagnostics=False):
     b = batch.buf
     hn = b.les_in.hn
     keys = _LES_IN_LEVELS + ("PS", "Rain") + (_LES_DIAG_LEVELS if diagnostics else ())
-    g1 = _LES_IN_LEVELS[:4]
-    g2 = tuple(k for k in keys if k not in g1)
-    ens.get_profiles_batched(g1, {k: hn[k] for k in g1})
-    b.les_in.upload_span(g1[0], g1[-1])                   # in flight while the remaining getters run
-    ens.get_profiles_batched(g2, {k: hn[k] for k in g2})
+    ens.get_profiles_batched(keys, {k: hn[k] for k in keys})
     ens.get_cloudfraction_batched(_index_map(batch), hn["A"])                 # spcpl.py:761-765
-    b.les_in.upload_span(_LES_IN_LEVELS[4], _LES_DIAG_LEVELS[-1] if diagnostics else "rain_last")
-    b.les_in.uploads_done()
+    b.les_in.upload()
     batch.profile_generation += 1
     prof = {k: hn[k] for k in keys + ("A",)}
     prof["_buffers"] = b
@@ -753,7 +694,7 @@ _BWD_KEYS = ("T", "QT", "QL", "QL_ice", "U", "V", "A")
 _BWD_OUT = ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A")
 
 
-def backward_batched(batch, profiles, dt_gcm, factor=1, conservative=False, download=True):
+def backward_batched(batch, profiles, dt_gcm, factor=1, conservative=False):
     """K3 (K4 when ``conservative``) for every column of ``batch``; ``profiles``: dict of device tensors
     T,QT,QL,QL_ice,U,V [n x nL], A [n x nG] (+ Rhobf for conservative).  Zf is recomputed from the geopotential
     in-kernel (same arithmetic as the forward pass: no height round trip).  Returns dict of HOST arrays, views
@@ -770,8 +711,7 @@ def backward_batched(batch, profiles, dt_gcm, factor=1, conservative=False, down
         plan.launch()
     else:
         eng.backward(batch.gcm, batch.zf, prof, float(factor), dt, Zf=None, conservative=conservative, zh=batch.zh, out=out)
-    if download:
-        b.bwd_out.download()
+    b.bwd_out.download()
     return {k: b.bwd_out.hn[k] for k in _BWD_OUT + ("start_index",)}
 
 
@@ -825,19 +765,7 @@ def set_gcm_tendencies_batched(gcm, les_models, profiles, dt_gcm, factor=1, writ
             raise RuntimeError("set_gcm_tendencies_batched: pass what get_les_profiles_batched() returned")
         if (write and writer is not None or conservative) and "Rhobf" not in profiles:
             raise RuntimeError("conservative coarsening / spifs output need get_les_profiles_batched(diagnostics=True)")
-        batch.bwd = backward_batched(batch, b.les_in.d, dt_gcm, factor, conservative, download=False)
-        ev1 = b.bwd_out.download_span("f_T", "f_QI")
-        ev2 = b.bwd_out.download_span("f_U", "start_index")
-        if hasattr(gcm, "set_profile_tendencies") and not (write and writer is not None):
-            ev1.synchronize()                     # setters of the first span while the second is on the wire
-            for var in ("T", "SH", "QL", "QI"):                                  # spcpl.py:537-540
-                gcm.set_profile_tendencies(var, les_models.grid_indices, _wrap("f_" + var, batch.bwd["f_" + var]))
-            ev2.synchronize()
-            for var in ("U", "V", "A"):                                          # spcpl.py:535-536, 541
-                gcm.set_profile_tendencies(var, les_models.grid_indices, _wrap("f_" + var, batch.bwd["f_" + var]))
-            return
-        ev1.synchronize()
-        ev2.synchronize()
+        batch.bwd = backward_batched(batch, b.les_in.d, dt_gcm, factor, conservative)
         if write and writer is not None:
             _write_backward(batch, b.les_in.d)
         if hasattr(gcm, "set_profile_tendencies"):

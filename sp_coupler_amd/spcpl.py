@@ -61,8 +61,11 @@ def get_engine():
 
 
 def set_engine(engine):
-    global _engine
+    """install (or, with None, drop) the engine; transfer buffers and launch plans bound to the old one are released"""
+    global _engine, _current
     _engine = engine
+    _buffers.clear()
+    _current = None
 
 
 def set_unit_wrapper(fn):
@@ -866,6 +869,10 @@ def variability_nudge_batched(les_models, DT, constantT=False, write=True):
         if constantT:                                                         # spcpl.py:634-636
             F["thl"].append(_num(les.get_field("THL")))
             F["ql"].append(_num(les.get_field("QL")))
+    shapes = {a.shape for a in F["qt"]} | {a.shape for a in F["qsat"]}
+    if len(shapes) != 1:
+        raise ValueError("variability_nudge_batched: one launch handles LES instances of ONE field shape, got %s; "
+                         "call it per group of equal shapes" % sorted(shapes))
     up = lambda rows: torch.from_numpy(numpy.ascontiguousarray(numpy.stack(rows))).to(dev, dt)      # noqa: E731
     T = {k: up(v) for k, v in F.items() if v}
     res = eng.variability_nudge(T["qt"], T["qsat"], up(Rs), T["ql_av"], T["qt_av"], T["ql_ref"], presf=T["presf"],

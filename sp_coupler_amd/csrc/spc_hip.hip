@@ -61,12 +61,6 @@ int fail(int code, const char *fmt, const char *a = "", long long b = 0, long lo
     return code;
 }
 
-int env_int_early(const char *name, int dflt)
-{
-    const char *e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
 // ---- constants: splib/sputils.py:14-20 ----------------------------------------------------------
 template <typename T> struct K {
     static constexpr T pref0 = T(1e5), rd = T(287.04), rv = T(461.5), cp = T(1004.), rlv = T(2.53e6),
@@ -165,54 +159,6 @@ template <int WT, typename T> __device__ __forceinline__ void stg(T *q, T v)
 template <typename T> __device__ __forceinline__ T div_grav(T x) { return SPC_DIV(x, K<T>::grav); }
 template <typename T> __device__ __forceinline__ T div_cp(T x) { return SPC_DIV(x, K<T>::cp); }
 template <typename T> __device__ __forceinline__ T div_pref0(T x) { return SPC_DIV(x, K<T>::pref0); }
-
-// x / dt for the launch-uniform dt of the forcings and tendencies (spcpl.py:328-333, 518-526), EXACTLY as IEEE
-// division rounds it, but without a division per value: with r = RN(1/dt) from the host,
-//     q0 = RN(x r);  rem = x - q0 dt (exact, one FMA);  q = RN(q0 + rem r)
-// is the correctly rounded quotient (Markstein) as long as nothing under- or overflows on the way.  That is
-// guaranteed for 2^-200 <= |dt| <= 2^200 (checked on the host: `fast`) and 2^-800 <= |x| <= 2^800 (checked per value:
-// zero, subnormal, huge, inf and NaN numerators take the true division); verified against `/` on 2.2e9 operand pairs
-// on the host, special significands included.  3 instructions instead of hipcc's 11-instruction expansion with its
-// quarter-rate v_rcp_f64.
-template <typename T> struct DtDiv {
-    T dt, rdt;
-    int fast;
-};
-
-__device__ __forceinline__ bool dt_num_ok(double a)
-{
-    const unsigned e = ((unsigned)__double2hiint(a) >> 20) & 0x7ffu;       // biased exponent
-    return (e - 223u) <= 1600u;                                            // 2^-800 .. 2^800
-}
-
-template <int N> __device__ __forceinline__ void div_by_dt(double (&x)[N], const DtDiv<double> &q)
-{
-#if SPC_EXP
-#pragma unroll
-    for (int k = 0; k < N; ++k) x[k] = SPC_DIV(x[k], q.dt);
-#else
-    bool ok = q.fast != 0;
-#pragma unroll
-    for (int k = 0; k < N; ++k) ok &= dt_num_ok(x[k]);
-    if (ok) {
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-            const double q0 = x[k] * q.rdt;
-            const double rem = __builtin_fma(-q0, q.dt, x[k]);
-            x[k] = __builtin_fma(rem, q.rdt, q0);
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < N; ++k) x[k] = x[k] / q.dt;
-    }
-#endif
-}
-
-template <int N> __device__ __forceinline__ void div_by_dt(float (&x)[N], const DtDiv<float> &q)
-{
-#pragma unroll
-    for (int k = 0; k < N; ++k) x[k] = SPC_DIV(x[k], q.dt);
-}
 
 // numpy NaN-aware "a < b" used by searchsorted (NaN sorts to the end)
 template <typename T> __device__ __forceinline__ bool np_lt(T a, T b) { return a < b || (b != b && a == a); }
@@ -379,7 +325,6 @@ template <typename T, bool FULL> struct FwdP {
     const T *U, *V, *Tm, *SH, *QL, *QI, *Pf, *Ph, *Zgfull, *Zghalf, *zf, *zh;
     const T *u_d, *v_d, *thl_d, *qt_d, *ql_d, *ps_d;
     T factor, dt;
-    DtDiv<T> dd;
     T *f_u, *f_v, *f_thl, *f_qt, *f_ql, *ql_ref, *f_ps;
     int32_t *idx;
     typename std::conditional<FULL, FwdOpt<T>, Empty>::type o;
@@ -393,7 +338,6 @@ template <typename T> struct BwdP {
     const T *t_d, *qt_d, *ql_d, *ql_ice_d, *u_d, *v_d, *A_prof;
     const T *zh, *Zh, *rhobf_d;    // conservative coarsening only (K4)
     T factor, dt;
-    DtDiv<T> dd;
     T *f_T, *f_SH, *f_QL, *f_QI, *f_U, *f_V, *f_A;
     int32_t *start_index;
 };
@@ -582,14 +526,11 @@ __global__ __launch_bounds__(BLOCK, SPC_K1_WAVES) void k_forward(const FwdP<T, F
             }
             interp_fields<5>(b, f0, f1, r);
             const T thl = r[0], qt = r[1], ql = r[2], u = r[3], v = r[4];               // spcpl.py:224-228
-            T fc[5] = {p.factor * (u - in.ud), p.factor * (v - in.vd), p.factor * (thl - in.thld), p.factor * (qt - in.qtd),
-                       p.factor * (ql - in.qld)};
-            div_by_dt<5>(fc, p.dd);                                           // .../dt_gcm, spcpl.py:328-333
-            stg<WT>(&p.f_u[o], fc[0]);                                        // spcpl.py:328
-            stg<WT>(&p.f_v[o], fc[1]);                                        // spcpl.py:329
-            stg<WT>(&p.f_thl[o], fc[2]);                                      // spcpl.py:330
-            stg<WT>(&p.f_qt[o], fc[3]);                                       // spcpl.py:331
-            stg<WT>(&p.f_ql[o], fc[4]);                                       // spcpl.py:333
+            stg<WT>(&p.f_u[o], p.factor * (u - in.ud) / p.dt);               // spcpl.py:328
+            stg<WT>(&p.f_v[o], p.factor * (v - in.vd) / p.dt);               // spcpl.py:329
+            stg<WT>(&p.f_thl[o], p.factor * (thl - in.thld) / p.dt);         // spcpl.py:330
+            stg<WT>(&p.f_qt[o], p.factor * (qt - in.qtd) / p.dt);            // spcpl.py:331
+            stg<WT>(&p.f_ql[o], p.factor * (ql - in.qld) / p.dt);            // spcpl.py:333
             stg<WT>(&p.ql_ref[o], ql);                                                         // spcpl.py:347-348
             if constexpr (FULL) {
                 if (OPT(u)) OPT(u)[o] = u;
@@ -767,15 +708,13 @@ template <typename T, int NG, int NL, int WT> __global__ __launch_bounds__(BLOCK
         } else {
             t_i = qt_i = ql_i = qlw_i = qli_i = u_i = v_i = x;
         }
-        T tn[7] = {p.factor * (t_i - in.tt),                                           // spcpl.py:518
-                   p.factor * ((qt_i - ql_i) - in.sh),                                 // spcpl.py:519
-                   p.factor * (qlw_i - in.ql),                                         // spcpl.py:520
-                   p.factor * (qli_i - in.qi),                                         // spcpl.py:521
-                   p.factor * (u_i - in.u),                                            // spcpl.py:524
-                   p.factor * (v_i - in.v),                                            // spcpl.py:525
-                   p.factor * (in.a_d - in.a)};                                        // spcpl.py:526
-        div_by_dt<7>(tn, p.dd);                                                        // .../ft
-        T f_T = tn[0], f_SH = tn[1], f_QL = tn[2], f_QI = tn[3], f_U = tn[4], f_V = tn[5], f_A = tn[6];
+        T f_T = p.factor * (t_i - in.tt) / p.dt;                                       // spcpl.py:518
+        T f_SH = p.factor * ((qt_i - ql_i) - in.sh) / p.dt;                            // spcpl.py:519
+        T f_QL = p.factor * (qlw_i - in.ql) / p.dt;                                    // spcpl.py:520
+        T f_QI = p.factor * (qli_i - in.qi) / p.dt;                                    // spcpl.py:521
+        T f_U = p.factor * (u_i - in.u) / p.dt;                                        // spcpl.py:524
+        T f_V = p.factor * (v_i - in.v) / p.dt;                                        // spcpl.py:525
+        T f_A = p.factor * (in.a_d - in.a) / p.dt;                                     // spcpl.py:526
         if (k < start_index) {  // `f[0:start_index] *= 0` (spcpl.py:527-533): -x -> -0, NaN stays NaN
             const T zero = T(0);
             f_T *= zero; f_SH *= zero; f_QL *= zero; f_QI *= zero; f_U *= zero; f_V *= zero; f_A *= zero;
@@ -916,16 +855,6 @@ __global__ __launch_bounds__(BLOCK) void k_copy8(double *dst, const double *src,
 }
 
 // ---- host side --------------------------------------------------------------------------------
-template <typename T> DtDiv<T> make_dtdiv(double dt)
-{
-    DtDiv<T> q;
-    q.dt = (T)dt;
-    q.rdt = (T)(1.0 / dt);                                   // RN(1/dt): the host divides in IEEE double too
-    const double m = dt < 0 ? -dt : dt;
-    q.fast = std::is_same<T, double>::value && m >= 0x1p-200 && m <= 0x1p200 && env_int_early("SPC_FAST_DTDIV", 1);
-    return q;
-}
-
 int floor_pow2(int n)
 {
     int p = 1;
@@ -1214,7 +1143,6 @@ template <typename T> int forward_impl(const spc_dims *d, const spc_forward_args
         CP(U); CP(V); p.Tm = (const T *)a->T; CP(SH); CP(QL); CP(QI); CP(Pf); CP(Ph); CP(Zgfull); CP(Zghalf);
         CP(zf); CP(zh); CP(u_d); CP(v_d); CP(thl_d); CP(qt_d); CP(ql_d); CP(ps_d);
         p.factor = (T)a->factor; p.dt = (T)a->dt;
-        p.dd = make_dtdiv<T>(a->dt);
         OP(f_u); OP(f_v); OP(f_thl); OP(f_qt); OP(f_ql); OP(ql_ref); OP(f_ps); p.idx = a->idx;
     };
     if (full) {
@@ -1296,7 +1224,6 @@ template <typename T> int backward_impl(const spc_dims *d, const spc_backward_ar
     p.Tm = (const T *)a->T; CP(SH); CP(QL); CP(QI); CP(U); CP(V); CP(A); CP(Zf); CP(Zgfull); CP(Zghalf); CP(zf);
     CP(t_d); CP(qt_d); CP(ql_d); CP(ql_ice_d); CP(u_d); CP(v_d); CP(A_prof); CP(zh); CP(Zh); CP(rhobf_d);
     p.factor = (T)a->factor; p.dt = (T)a->dt;
-    p.dd = make_dtdiv<T>(a->dt);
     OP(f_T); OP(f_SH); OP(f_QL); OP(f_QI); OP(f_U); OP(f_V); OP(f_A); p.start_index = a->start_index;
     if constexpr (std::is_same<T, double>::value) {
         if (!cons && geo != 0 && d->cols_per_block == 0 && env_int("SPC_V2", 1) &&

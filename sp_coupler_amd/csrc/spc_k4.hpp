@@ -134,15 +134,13 @@ template <typename T, int NG = 0, int NL = 0> __global__ __launch_bounds__(BLOCK
         const int start_index = ss_left_neg(Zf, nG, h[nL - 1]);                        // spcpl.py:498
         const T X0 = X[k], X1 = X[nG + k], X2 = X[2 * nG + k], X3 = X[3 * nG + k], X4 = X[4 * nG + k], X5 = X[5 * nG + k],
                 X6 = X[6 * nG + k];
-        T tn[7] = {p.factor * (X0 - in.tt),                                            // spcpl.py:518
-                   p.factor * ((X1 - X2) - in.sh),                                     // spcpl.py:519
-                   p.factor * (X3 - in.ql),                                            // spcpl.py:520
-                   p.factor * (X4 - in.qi),                                            // spcpl.py:521
-                   p.factor * (X5 - in.u),                                             // spcpl.py:524
-                   p.factor * (X6 - in.v),                                             // spcpl.py:525
-                   p.factor * (in.a_d - in.a)};                                        // spcpl.py:526
-        div_by_dt<7>(tn, p.dd);
-        T f_T = tn[0], f_SH = tn[1], f_QL = tn[2], f_QI = tn[3], f_U = tn[4], f_V = tn[5], f_A = tn[6];
+        T f_T = p.factor * (X0 - in.tt) / p.dt;                                        // spcpl.py:518
+        T f_SH = p.factor * ((X1 - X2) - in.sh) / p.dt;                                // spcpl.py:519
+        T f_QL = p.factor * (X3 - in.ql) / p.dt;                                       // spcpl.py:520
+        T f_QI = p.factor * (X4 - in.qi) / p.dt;                                       // spcpl.py:521
+        T f_U = p.factor * (X5 - in.u) / p.dt;                                         // spcpl.py:524
+        T f_V = p.factor * (X6 - in.v) / p.dt;                                         // spcpl.py:525
+        T f_A = p.factor * (in.a_d - in.a) / p.dt;                                     // spcpl.py:526
         if (k < start_index) {                                                         // spcpl.py:527-533
             const T zero = T(0);
             f_T *= zero; f_SH *= zero; f_QL *= zero; f_QI *= zero; f_U *= zero; f_V *= zero; f_A *= zero;

@@ -212,17 +212,11 @@ __global__ __launch_bounds__(BLOCK) void k_forward_v2(const FwdP<double, false> 
                 // record order: thl, qt, ql, u, v
                 const int64_t o0 = sb.o0;
                 const int lim2 = sb.lim2;
-                double fc[10] = {p.factor * (ra[3] - lu[it].x), p.factor * (rb[3] - lu[it].y),        // f_u   spcpl.py:328
-                                 p.factor * (ra[4] - lv[it].x), p.factor * (rb[4] - lv[it].y),        // f_v   :329
-                                 p.factor * (ra[0] - lthl[it].x), p.factor * (rb[0] - lthl[it].y),    // f_thl :330
-                                 p.factor * (ra[1] - lqt[it].x), p.factor * (rb[1] - lqt[it].y),      // f_qt  :331
-                                 p.factor * (ra[2] - lql[it].x), p.factor * (rb[2] - lql[it].y)};     // f_ql  :333
-                div_by_dt<10>(fc, p.dd);
-                st2<WT>(p.f_u + o0, e, lim2, d2{fc[0], fc[1]});
-                st2<WT>(p.f_v + o0, e, lim2, d2{fc[2], fc[3]});
-                st2<WT>(p.f_thl + o0, e, lim2, d2{fc[4], fc[5]});
-                st2<WT>(p.f_qt + o0, e, lim2, d2{fc[6], fc[7]});
-                st2<WT>(p.f_ql + o0, e, lim2, d2{fc[8], fc[9]});
+                st2<WT>(p.f_u + o0, e, lim2, d2{SPC_DIV(p.factor * (ra[3] - lu[it].x), p.dt), SPC_DIV(p.factor * (rb[3] - lu[it].y), p.dt)});       // :328
+                st2<WT>(p.f_v + o0, e, lim2, d2{SPC_DIV(p.factor * (ra[4] - lv[it].x), p.dt), SPC_DIV(p.factor * (rb[4] - lv[it].y), p.dt)});       // :329
+                st2<WT>(p.f_thl + o0, e, lim2, d2{SPC_DIV(p.factor * (ra[0] - lthl[it].x), p.dt), SPC_DIV(p.factor * (rb[0] - lthl[it].y), p.dt)}); // :330
+                st2<WT>(p.f_qt + o0, e, lim2, d2{SPC_DIV(p.factor * (ra[1] - lqt[it].x), p.dt), SPC_DIV(p.factor * (rb[1] - lqt[it].y), p.dt)});    // :331
+                st2<WT>(p.f_ql + o0, e, lim2, d2{SPC_DIV(p.factor * (ra[2] - lql[it].x), p.dt), SPC_DIV(p.factor * (rb[2] - lql[it].y), p.dt)});    // :333
                 st2<WT>(p.ql_ref + o0, e, lim2, d2{ra[2], rb[2]});                                                                   // :347-348
             }
         }
@@ -379,15 +373,13 @@ __global__ __launch_bounds__(BLOCK) void k_backward_v2(const BwdP<double> p)
             const double tt = s ? gT[it].y : gT[it].x, sh = s ? gSH[it].y : gSH[it].x, ql = s ? gQL[it].y : gQL[it].x;
             const double qi = s ? gQI[it].y : gQI[it].x, uu = s ? gU[it].y : gU[it].x, vv = s ? gV[it].y : gV[it].x;
             const double aa = s ? gA[it].y : gA[it].x, a_d = s ? ad1[it] : ad0[it];
-            double tn[7] = {p.factor * (r[0] - tt),                                        // spcpl.py:518
-                            p.factor * ((r[1] - r[2]) - sh),                               // spcpl.py:519
-                            p.factor * (r[3] - ql),                                        // spcpl.py:520
-                            p.factor * (r[4] - qi),                                        // spcpl.py:521
-                            p.factor * (r[5] - uu),                                        // spcpl.py:524
-                            p.factor * (r[6] - vv),                                        // spcpl.py:525
-                            p.factor * (a_d - aa)};                                        // spcpl.py:526
-            div_by_dt<7>(tn, p.dd);
-            double f_T = tn[0], f_SH = tn[1], f_QL = tn[2], f_QI = tn[3], f_U = tn[4], f_V = tn[5], f_A = tn[6];
+            double f_T = SPC_DIV(p.factor * (r[0] - tt), p.dt);                                    // spcpl.py:518
+            double f_SH = SPC_DIV(p.factor * ((r[1] - r[2]) - sh), p.dt);                          // spcpl.py:519
+            double f_QL = SPC_DIV(p.factor * (r[3] - ql), p.dt);                                   // spcpl.py:520
+            double f_QI = SPC_DIV(p.factor * (r[4] - qi), p.dt);                                   // spcpl.py:521
+            double f_U = SPC_DIV(p.factor * (r[5] - uu), p.dt);                                    // spcpl.py:524
+            double f_V = SPC_DIV(p.factor * (r[6] - vv), p.dt);                                    // spcpl.py:525
+            double f_A = SPC_DIV(p.factor * (a_d - aa), p.dt);                                     // spcpl.py:526
             if (k < start_index) {  // `f[0:start_index] *= 0` (spcpl.py:527-533): -x -> -0, NaN stays NaN
                 f_T *= 0.0; f_SH *= 0.0; f_QL *= 0.0; f_QI *= 0.0; f_U *= 0.0; f_V *= 0.0; f_A *= 0.0;
             }

@@ -51,20 +51,16 @@ def main():
             p = {k: torch.from_numpy(v).to(eng.device, dtype) for k, v in prof.items()}
             data.append((g, torch.from_numpy(zf).to(eng.device, dtype), torch.from_numpy(zh).to(eng.device, dtype), p))
         for cb, var in [(int(x), v) for x in a.cbs.split(",") for v in (a.variants.split(";") if a.variants else [""])]:
-            for k in ("SPC_V2", "SPC_V2_K1", "SPC_V2_K3", "SPC_V2_REMAP", "SPC_FAST_DTDIV"):
+            for k in ("SPC_V2", "SPC_V2_K1", "SPC_V2_K3", "SPC_V2_REMAP", "SPC_V2_PERSIST"):
                 os.environ.pop(k, None)
             if var:
                 v, _, r = var.partition(":")
                 if v == "v1":
                     os.environ["SPC_V2"] = "0"
-                elif v == "auto":
-                    pass
                 else:
                     os.environ["SPC_V2_K1"] = os.environ["SPC_V2_K3"] = v
                 if r.startswith("r"):
                     os.environ["SPC_V2_REMAP"] = r[1:]
-                if r.startswith("d"):                       # d0: true IEEE division by dt instead of reciprocal + FMA correction
-                    os.environ["SPC_FAST_DTDIV"] = r[1:]
             pl = [eng.plan_exchange(g, zf, zh, p, 1.0, 1.0, 900.0, cols_per_block=cb) for g, zf, zh, p in data]   # as bench.py
             fpl, bpl = [x[0] for x in pl], [x[1] for x in pl]
             res = {}

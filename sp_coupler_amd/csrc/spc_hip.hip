@@ -417,8 +417,10 @@ constexpr int cfloor_pow2(int n) { int p = 1; while (p * 2 <= n) p *= 2; return 
 #ifndef SPC_K3_WAVES
 #define SPC_K3_WAVES 1
 #endif
-template <typename T, bool FULL, int NG, int NL, int WT>
-__global__ __launch_bounds__(BLOCK, SPC_K1_WAVES) void k_forward(const FwdP<T, FULL> p)
+// BLK: workgroup size.  256 everywhere except the small-batch path (small_block()): there one workgroup of 512 / 1024
+// threads takes 2 / 4 columns, still one work item per thread, so that <= 256 workgroups cover the batch.
+template <typename T, bool FULL, int NG, int NL, int WT, int BLK = BLOCK>
+__global__ __launch_bounds__(BLK, SPC_K1_WAVES) void k_forward(const FwdP<T, FULL> p)
 {
     const DimsP &d = p.d;
     // The ~20 optional pointers of the FULL variant are fetched from the kernarg block where they are used (a
@@ -452,7 +454,7 @@ __global__ __launch_bounds__(BLOCK, SPC_K1_WAVES) void k_forward(const FwdP<T, F
         pre_zgh = ldg(&p.Zghalf[gh + (nG - 1 - m)]);
         pre_zs = ldg(&p.Zghalf[gh + nG]);
     }
-    const int sc = BLOCK - 1 - tid;          // the LAST threads own the per-column scalars
+    const int sc = BLK - 1 - tid;          // the LAST threads own the per-column scalars
     T sc_ps = T(0), sc_psd = T(0), sc_rain = T(0), sc_rl = T(0);
     if (sc < ncol) {
         sc_ps = ldg(&p.Ph[(col0 + sc) * pitchGh + nG]);                                   // spcpl.py:246
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(BLOCK, SPC_K1_WAVES) void k_forward(const FwdP<T, F
     }
     if (p.idx) {  // stage the LES half levels for the fused index map
         const int nz = d.shared_grid ? nL : n2;
-        for (int e = tid; e < nz; e += BLOCK) {
+        for (int e = tid; e < nz; e += BLK) {
             const int c = e / nL, l = e - c * nL;
             lzh[e] = d.shared_grid ? p.zh[e] : p.zh[(col0 + c) * pitchL + l];
         }
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(BLOCK, SPC_K1_WAVES) void k_forward(const FwdP<T, F
     STAMP(1);
 
     // ---- phase 1: load GCM levels (flat over the [ncol x nG] slab), convert, stage reversed ----
-    for (int e = tid; e < n1; e += BLOCK) {
+    for (int e = tid; e < n1; e += BLK) {
         const int c = e / nG, k = e - c * nG;
         const int64_t col = col0 + c, g = col * pitchG + k;
         const T zsurf = ldg(&p.Zghalf[col * pitchGh + nG]);
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(BLOCK, SPC_K1_WAVES) void k_forward(const FwdP<T, F
     }
 
     // ---- phase 2: LES levels (interpolate 5 fields, form the forcings) and index-map entries ------
-    for (int e = tid; e < nitems; e += BLOCK) {
+    for (int e = tid; e < nitems; e += BLK) {
         if (e < n2) {
             const int c = e / nL, l = e - c * nL;
             const int64_t col = col0 + c, o = col * pitchL + l;
@@ -553,7 +555,7 @@ __global__ __launch_bounds__(BLOCK, SPC_K1_WAVES) void k_forward(const FwdP<T, F
     // ---- half-level heights (optional output): spcpl.py:197 --------------------------------------
     if constexpr (FULL) {
         if (OPT(Zh)) {
-            for (int e = tid; e < ncol * (nG + 1); e += BLOCK) {
+            for (int e = tid; e < ncol * (nG + 1); e += BLK) {
                 const int c = e / (nG + 1), k = e - c * (nG + 1);
                 const int64_t gh = (col0 + c) * pitchGh;
                 OPT(Zh)[gh + k] = div_grav(ldg(&p.Zghalf[gh + k]) - ldg(&p.Zghalf[gh + nG]));
@@ -605,7 +607,7 @@ template <typename T> __device__ __forceinline__ GcmIn<T> load_gcm(const BwdP<T>
     return r;
 }
 
-template <typename T, int NG, int NL, int WT> __global__ __launch_bounds__(BLOCK, SPC_K3_WAVES) void k_backward(const BwdP<T> p)
+template <typename T, int NG, int NL, int WT, int BLK = BLOCK> __global__ __launch_bounds__(BLK, SPC_K3_WAVES) void k_backward(const BwdP<T> p)
 {
     const DimsP &d = p.d;
     const int nG = NG ? NG : d.nG, nL = NL ? NL : d.nL, cb = d.cb, tid = threadIdx.x;
@@ -652,7 +654,7 @@ template <typename T, int NG, int NL, int WT> __global__ __launch_bounds__(BLOCK
         pre = load_gcm(p, cg + k, cg + (nG - 1 - k));
     }
 
-    for (int e = tid; e < n2; e += BLOCK) {
+    for (int e = tid; e < n2; e += BLK) {
         const int c = e / nL, l = e - c * nL;
         const Stage st = (e == tid) ? st0 : load_stage((col0 + c) * pitchL + l);
         T *const s = lds + (size_t)c * per_col + l;
@@ -665,15 +667,15 @@ template <typename T, int NG, int NL, int WT> __global__ __launch_bounds__(BLOCK
         if (!d.shared_grid) lh[e] = st.h;
     }
     if (d.shared_grid)
-        for (int e = tid; e < nL; e += BLOCK) lh[e] = (e == tid) ? hs0 : ldg(&p.zf[e]);
-    for (int e = tid; e < n1; e += BLOCK) {
+        for (int e = tid; e < nL; e += BLK) lh[e] = (e == tid) ? hs0 : ldg(&p.zf[e]);
+    for (int e = tid; e < n1; e += BLK) {
         const int c = e / nG, k = e - c * nG;
         const int64_t col = col0 + c;
         lds[(size_t)c * per_col + 6 * nL + k] = (e == tid) ? zf0 : load_zf(col, col * pitchG + k);
     }
     __syncthreads();
 
-    for (int e = tid; e < n1; e += BLOCK) {
+    for (int e = tid; e < n1; e += BLK) {
         const int c = e / nG, k = e - c * nG;
         const int64_t col = col0 + c, cg = col * pitchG, g = cg + k;
         const T *const s = lds + (size_t)c * per_col;
@@ -1021,6 +1023,19 @@ bool aligned16(std::initializer_list<const void *> ptrs)
     return true;
 }
 
+// Small batches run ONE round of workgroups and are bound by latency, not bandwidth: there fewer, larger workgroups
+// win.  2 / 4 columns per workgroup of 512 / 1024 threads (still one work item per thread, so the per-thread chain is
+// unchanged) cover <= 1024 columns with <= 256 workgroups -- one per CU -- and the grid is dispatched in a half / a
+// quarter of the time.  Measured (tools/ab_blocks.sh, pre-heated, profiles/r02_ab_blocks.log): K1 8.5 -> 7.1 us and
+// K3 8.1 -> 7.8 us at 1024 columns, K1 6.4 -> 5.4 us at 512; slower from 1536 columns on.  Returns the columns per
+// workgroup (workgroup = 256 x that) or 0 = the 256-thread path.  SPC_SMALL_BLOCK=0 disables it (A/B).
+int small_block(const spc_dims *d, int items_per_col)
+{
+    if (d->cols_per_block != 0 || items_per_col > BLOCK || d->n_cols <= 256 || d->n_cols > 1024) return 0;
+    if (!env_int("SPC_SMALL_BLOCK", 1)) return 0;
+    return d->n_cols <= 512 ? 2 : 4;
+}
+
 struct V2Choice { int cb, block; };
 
 // Measured choice per pass and batch size (same-box A/B of every variant against the first-generation kernels,
@@ -1128,7 +1143,15 @@ template <typename T> int forward_impl(const spc_dims *d, const spc_forward_args
     static const KLean klean[2][4] = {
         {k_forward<T, false, 0, 0, 0>, k_forward<T, false, 91, 160, 0>, k_forward<T, false, 137, 512, 0>, k_forward<T, false, 19, 160, 0>},
         {k_forward<T, false, 0, 0, 1>, k_forward<T, false, 91, 160, 1>, k_forward<T, false, 137, 512, 1>, k_forward<T, false, 19, 160, 1>}};
-    const int cb = full ? pick_cb(d, 0, with_idx, sizeof(T), kfull[0][geo]) : pick_cb(d, 0, with_idx, sizeof(T), klean[0][geo]);
+    static const KLean klean512[2][4] = {
+        {k_forward<T, false, 0, 0, 0, 512>, k_forward<T, false, 91, 160, 0, 512>, k_forward<T, false, 137, 512, 0>, k_forward<T, false, 19, 160, 0, 512>},
+        {k_forward<T, false, 0, 0, 1, 512>, k_forward<T, false, 91, 160, 1, 512>, k_forward<T, false, 137, 512, 1>, k_forward<T, false, 19, 160, 1, 512>}};
+    static const KLean klean1024[2][4] = {
+        {k_forward<T, false, 0, 0, 0, 1024>, k_forward<T, false, 91, 160, 0, 1024>, k_forward<T, false, 137, 512, 0>, k_forward<T, false, 19, 160, 0, 1024>},
+        {k_forward<T, false, 0, 0, 1, 1024>, k_forward<T, false, 91, 160, 1, 1024>, k_forward<T, false, 137, 512, 1>, k_forward<T, false, 19, 160, 1, 1024>}};
+    // (the 137 <-> 512 slots hold the 256-thread kernels: 649 work items per column never qualify for small_block)
+    const int sb = full ? 0 : small_block(d, d->nL + (with_idx ? d->nG : 0));
+    const int cb = sb ? sb : (full ? pick_cb(d, 0, with_idx, sizeof(T), kfull[0][geo]) : pick_cb(d, 0, with_idx, sizeof(T), klean[0][geo]));
     const int wt = small_batch(d->n_cols * (int64_t)((6 * d->nL + 1) * sizeof(T) + (with_idx ? d->nG * 4 : 0)));
     size_t per_col, fixed;
     lds_elems(d, 0, with_idx, &per_col, &fixed);
@@ -1164,8 +1187,9 @@ template <typename T> int forward_impl(const spc_dims *d, const spc_forward_args
                 fill(p);
             }
         }
-        if ((rc = ensure_lds(klean[wt][geo], smem, "forward"))) return rc;
-        hipLaunchKernelGGL(klean[wt][geo], dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
+        const KLean kern = sb == 4 ? klean1024[wt][geo] : (sb == 2 ? klean512[wt][geo] : klean[wt][geo]);
+        if ((rc = ensure_lds(kern, smem, "forward"))) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(sb ? BLOCK * sb : BLOCK), smem, (hipStream_t)stream, p);
     }
     return launch_status("k_forward");
 }
@@ -1213,12 +1237,20 @@ template <typename T> int backward_impl(const spc_dims *d, const spc_backward_ar
         {k_backward<T, 0, 0, 0>, k_backward<T, 91, 160, 0>, k_backward<T, 137, 512, 0>, k_backward<T, 19, 160, 0>},
         {k_backward<T, 0, 0, 1>, k_backward<T, 91, 160, 1>, k_backward<T, 137, 512, 1>, k_backward<T, 19, 160, 1>}};
     static const KB kc[4] = {k_backward_cons2<T, 0, 0>, k_backward_cons2<T, 91, 160>, k_backward_cons2<T, 137, 512>, k_backward_cons2<T, 19, 160>};
-    const int cb = cons ? pick_cb(d, 4, false, sizeof(T), kc[geo]) : pick_cb(d, 1, false, sizeof(T), kb[0][geo]);
+    static const KB kb512[2][4] = {
+        {k_backward<T, 0, 0, 0, 512>, k_backward<T, 91, 160, 0, 512>, k_backward<T, 137, 512, 0>, k_backward<T, 19, 160, 0, 512>},
+        {k_backward<T, 0, 0, 1, 512>, k_backward<T, 91, 160, 1, 512>, k_backward<T, 137, 512, 1>, k_backward<T, 19, 160, 1, 512>}};
+    static const KB kb1024[2][4] = {
+        {k_backward<T, 0, 0, 0, 1024>, k_backward<T, 91, 160, 0, 1024>, k_backward<T, 137, 512, 0>, k_backward<T, 19, 160, 0, 1024>},
+        {k_backward<T, 0, 0, 1, 1024>, k_backward<T, 91, 160, 1, 1024>, k_backward<T, 137, 512, 1>, k_backward<T, 19, 160, 1, 1024>}};
+    const int sb = cons ? 0 : small_block(d, d->nL > d->nG ? d->nL : d->nG);
+    const int cb = sb ? sb : (cons ? pick_cb(d, 4, false, sizeof(T), kc[geo]) : pick_cb(d, 1, false, sizeof(T), kb[0][geo]));
     const int wt = small_batch(d->n_cols * (int64_t)(7 * d->nG * sizeof(T)));
     size_t per_col, fixed;
     lds_elems(d, cons ? 4 : 1, false, &per_col, &fixed);
     const size_t smem = (per_col * cb + fixed) * sizeof(T);
-    if ((rc = cons ? ensure_lds(kc[geo], smem, "backward (conservative)") : ensure_lds(kb[wt][geo], smem, "backward"))) return rc;
+    const KB kbw = sb == 4 ? kb1024[wt][geo] : (sb == 2 ? kb512[wt][geo] : kb[wt][geo]);
+    if ((rc = cons ? ensure_lds(kc[geo], smem, "backward (conservative)") : ensure_lds(kbw, smem, "backward"))) return rc;
     BwdP<T> p;
     p.d = make_dims(d, cb);
     p.Tm = (const T *)a->T; CP(SH); CP(QL); CP(QI); CP(U); CP(V); CP(A); CP(Zf); CP(Zgfull); CP(Zghalf); CP(zf);
@@ -1238,7 +1270,7 @@ template <typename T> int backward_impl(const spc_dims *d, const spc_backward_ar
     if (cons)
         hipLaunchKernelGGL(kc[geo], dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL(kb[wt][geo], dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(kbw, dim3(grid), dim3(sb ? BLOCK * sb : BLOCK), smem, (hipStream_t)stream, p);
     return launch_status(cons ? "k_backward_cons" : "k_backward");
 }
 

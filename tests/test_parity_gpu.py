@@ -534,3 +534,65 @@ def test_exner_power_accuracy_and_special_values(eng):
     ulp = numpy.abs(got[fin] - want[fin]) / numpy.spacing(numpy.abs(want[fin]))
     assert ulp.max() <= 2.0, ulp.max()
     assert (ulp <= 1.0).mean() > 0.999
+
+
+@pytest.mark.parametrize("nG,nL,per_col,pad", [(91, 160, False, 0), (19, 160, False, 0), (60, 100, False, 0),
+                                              (91, 160, True, 0), (91, 160, False, 3), (120, 136, False, 0)])
+def test_small_batch_large_workgroups(eng, nG, nL, per_col, pad, monkeypatch):
+    """257..1024 columns run 2 / 4 columns per workgroup of 512 / 1024 threads (spc_hip.hip:small_block): every size
+    class, ragged last workgroups, compile-time and run-time geometries, per-column grids, padded pitches -- bit-checked
+    against the plain-C oracle, and bit-equal to the 256-thread path (SPC_SMALL_BLOCK=0)."""
+    import ctypes
+    sptr = ctypes.c_void_p(torch.cuda.current_stream(eng.device).cuda_stream)
+    for n in (257, 300, 512, 513, 777, 1023, 1024):
+        gcm, zf, zh, prof = synthetic.make_batch(n, nG, nL, seed=8800 + n, per_column_grid=per_col)
+        g = {k: _pad_pitch(v, pad) for k, v in to_dev(gcm, eng.device).items()}
+        p = {k: _pad_pitch(v, pad) for k, v in to_dev(prof, eng.device).items()}
+        zf_d = _pad_pitch(torch.from_numpy(zf).to(eng.device), pad)
+        zh_d = _pad_pitch(torch.from_numpy(zh).to(eng.device), pad)
+        ref_f = oracle_c.forward(gcm, zf, zh, prof, FACTOR, DT, couple_surface=False)
+        ref_b = oracle_c.backward(gcm, None, zf, prof, FACTOR, DT)
+        outs = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("SPC_SMALL_BLOCK", mode)
+            fp, bp = eng.plan_exchange(g, zf_d, zh_d, p, FACTOR, FACTOR, DT)
+            for t in list(fp.outputs.values()) + list(bp.outputs.values()):
+                t.fill_(float("nan")) if t.is_floating_point() else t.fill_(-7)
+            fp.launch_raw(sptr)
+            bp.launch_raw(sptr)
+            bs = eng.backward(g, zf_d, p, FACTOR, DT)              # with start_index
+            torch.cuda.synchronize()
+            outs[mode] = {**{k: host(v) for k, v in fp.outputs.items()}, **{k: host(v) for k, v in bp.outputs.items()},
+                          "start_index": host(bs["start_index"]), "f_T2": host(bs["f_T"])}
+        o = outs["1"]
+        tag = "n=%d " % n
+        assert_bits(tag + "idx", o["idx"], ref_f["idx"])
+        for k in ("f_u", "f_v", "f_qt", "f_ql", "ql_ref", "f_ps"):
+            assert_bits(tag + k, o[k], ref_f[k])
+        assert_close_scaled(tag + "f_thl", o["f_thl"], ref_f["f_thl"], 8 * EPS, numpy.abs(ref_f["thl"]).max() * abs(FACTOR) / DT)
+        for k in ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A"):
+            assert_bits(tag + k, o[k], ref_b[k])
+        assert_bits(tag + "start_index", o["start_index"], ref_b["start_index"])
+        assert_bits(tag + "f_T (start_index launch)", o["f_T2"], ref_b["f_T"])
+        for k in o:                                                  # both workgroup shapes: the same bits (f_thl too)
+            assert_bits(tag + k + " (large vs 256-thread workgroups)", o[k], outs["0"][k])
+
+
+def test_small_batch_large_workgroups_f32(eng):
+    from sp_coupler_amd.engine import Engine
+    e32 = Engine("cuda:0", dtype=torch.float32)
+    for n in (400, 1000):
+        gcm, zf, zh, prof = synthetic.make_batch(n, 91, 160, seed=8900 + n)
+        g32 = {k: torch.from_numpy(v).to(e32.device, torch.float32) for k, v in gcm.items()}
+        p32 = {k: torch.from_numpy(v).to(e32.device, torch.float32) for k, v in prof.items()}
+        zf32, zh32 = torch.from_numpy(zf).to(e32.device, torch.float32), torch.from_numpy(zh).to(e32.device, torch.float32)
+        fp, bp = e32.plan_exchange(g32, zf32, zh32, p32, FACTOR, FACTOR, DT)
+        fp.launch()
+        bp.launch()
+        torch.cuda.synchronize()
+        ref_f = orc.forward_batched(gcm, prof, zf, zh, FACTOR, DT, couple_surface=False)
+        ref_b = orc.backward_batched(gcm, ref_f["Zf"], prof, zf, FACTOR, DT)
+        for k, ref in (("f_u", ref_f), ("f_qt", ref_f), ("f_thl", ref_f), ("f_T", ref_b), ("f_U", ref_b)):
+            got = host((fp.outputs if k in fp.outputs else bp.outputs)[k]).astype(numpy.float64)
+            scale = numpy.abs(ref[k]).max()
+            assert numpy.abs(got - ref[k]).max() <= 2e-3 * scale, k

@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--cbs", default="0")
     ap.add_argument("--levels", default="91,160")
     ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--heat-ms", type=float, default=40.0, help="run the kernel this long before timing it: the first ~20 ms "
+                    "after an idle gap run 10-13 %% slower (clock ramp, profiles/r02_shortrun_clock_ramp.log)")
+    ap.add_argument("--min-ms", type=float, default=10.0, help="timed region at least this long (iters is raised to fit)")
     ap.add_argument("--dtype", default="f64")
     ap.add_argument("--tag", default="")
     ap.add_argument("--variants", default="", help="semicolon list of kernel variants to A/B in this process: "
@@ -65,16 +68,24 @@ def main():
             fpl, bpl = [x[0] for x in pl], [x[1] for x in pl]
             res = {}
             for name, plans in (("K1", fpl), ("K3", bpl)):
-                for i in range(20):
-                    plans[i % rot].launch_raw(sptr)
-                torch.cuda.synchronize()
+                import time
+                t0, done = time.perf_counter(), 0
+                while True:                                   # pre-heat: steady clocks before the timed loop
+                    for i in range(50):
+                        plans[i % rot].launch_raw(sptr)
+                    torch.cuda.synchronize()
+                    done += 50
+                    if (time.perf_counter() - t0) * 1e3 >= a.heat_ms:
+                        break
+                per = (time.perf_counter() - t0) / done
+                iters = max(a.iters, int(a.min_ms * 1e-3 / per))
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
-                for i in range(a.iters):
+                for i in range(iters):
                     plans[i % rot].launch_raw(sptr)
                 e1.record(stream)
                 torch.cuda.synchronize()
-                res[name] = e0.elapsed_time(e1) * 1e3 / a.iters
+                res[name] = e0.elapsed_time(e1) * 1e3 / iters
             print("%s %-10s n=%d %d<->%d %s cb=%d rot=%d | K1 %.2f us %.0f GB/s (%.1f%% of 8TB/s) | K3 %.2f us %.0f GB/s (%.1f%%)" % (
                 a.tag, var, n, nG, nL, a.dtype, cb, rot, res["K1"], n * fb / res["K1"] / 1e3, n * fb / res["K1"] / 1e3 / 80,
                 res["K3"], n * bb / res["K3"] / 1e3, n * bb / res["K3"] / 1e3 / 80), flush=True)

@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s measured copy)
 KERNEL_LAUNCHES = 400   # back-to-back launches per per-kernel HIP-event measurement (independent of --steps)
+HEAT_MS = 40.0          # GPU work in front of every timed loop (clock ramp after idle: Workload.heat)
 
 
 def algorithmic_bytes(nG, nL, esize=8, shared_grid=True):
@@ -224,17 +225,30 @@ class Workload:
         self.fplans[i % self.rotate].launch_raw(sptr)
         self.bplans[i % self.rotate].launch_raw(sptr)
 
+    def heat(self, sptr, ms=HEAT_MS, plans=None):
+        """Whole steps (or launches of `plans`) for `ms` of wall time: an MI355X that has idled for >= 50 ms runs its
+        first ~20 ms of work 10-13 % slower (clock ramp, profiles/r02_shortrun_clock_ramp.log), so every timed loop of
+        this file starts from a GPU that has just been busy for longer than that."""
+        import torch
+        t0, i = time.perf_counter(), 0
+        while (time.perf_counter() - t0) * 1e3 < ms:
+            for _ in range(16):
+                if plans is None:
+                    self.step(i, sptr)
+                else:
+                    plans[i % self.rotate].launch_raw(sptr)
+                i += 1
+            torch.cuda.synchronize()
+
     def kernel_times(self, stream, sptr, launches=KERNEL_LAUNCHES):
         """Average duration of K1 alone and K3 alone: HIP events (recorded on the launch stream) around `launches`
         back-to-back launches of the one kernel over the rotating batches (inter-kernel gap ~40 ns in rocprofv3
-        traces); the figure rocprofv3 --kernel-trace --stats reproduces (profiles/)."""
+        traces), after heat(); the figure rocprofv3 --kernel-trace --stats reproduces (profiles/)."""
         import torch
         res = {}
         for name, plans in (("k1", self.fplans), ("k3", self.bplans)):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            for i in range(16):
-                plans[i % self.rotate].launch_raw(sptr)
-            torch.cuda.synchronize()
+            self.heat(sptr, plans=plans)
             e0.record(stream)
             for i in range(launches):
                 plans[i % self.rotate].launch_raw(sptr)
@@ -316,11 +330,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # The per-kernel HIP-event pass and the copy-rate probe run BEFORE the timed region.  They are measurements in
-    # their own right, and they double as the clock pre-heat: after an idle gap (>= 50 ms, e.g. the host-side batch
-    # generation above) an MI355X runs the first ~20 ms of work 10-13 % slower than steady state
-    # (profiles/r02_shortrun_clock_ramp.log, tools/shortrun.py), which is longer than the driver's whole
-    # `--warmup 5 --steps 20` region.  `cold_clock` below reports the same K steps taken straight after an idle gap.
+    # The per-kernel HIP-event pass and the copy-rate probe run BEFORE the timed region, each behind Workload.heat():
+    # after an idle gap (>= 50 ms, e.g. the host-side batch generation above) an MI355X runs the first ~20 ms of work
+    # 10-13 % slower than steady state (profiles/r02_shortrun_clock_ramp.log, tools/shortrun.py), which is longer than
+    # the driver's whole `--warmup 5 --steps 20` region.  `cold_clock` below reports the same W + K taken straight
+    # after an idle gap.
     ab = algorithmic_bytes(nG, nL)
     k1_us = k3_us = None
     kdiag = {}
@@ -343,6 +357,7 @@ def main():
         copy_gbs = 2.0 * src.numel() * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
         del src, dst
 
+    wl.heat(sptr)
     for i in range(args.warmup):
         wl.step(i, sptr)
     fence()
@@ -376,9 +391,7 @@ def main():
     if world == 1 and not args.no_small_batch and not args.no_kernel_events and cfg != 2:
         n2, nG2, nL2, seed2 = synthetic.CONFIGS[2]
         w2 = Workload(eng, n2, nG2, nL2, seed2, 8, factor, dt_gcm, args.cols_per_block)
-        for i in range(200):
-            w2.step(i, sptr)
-        torch.cuda.synchronize()
+        w2.heat(sptr)
         t2 = time.perf_counter()
         for i in range(2000):
             w2.step(i, sptr)

@@ -1038,19 +1038,17 @@ int small_block(const spc_dims *d, int items_per_col)
 
 struct V2Choice { int cb, block; };
 
-// Measured choice per pass and batch size (same-box A/B of every variant against the first-generation kernels,
-// profiles/r02_kbench_variants.log): the second-generation K1 wins 2-4 % between ~6k and ~65k columns (the
-// per-GPU shard sizes of configs 3-4), the 8-column K3 wins 7 % from ~200k columns; elsewhere the first-generation
-// kernels are as fast or faster and stay in use (cb = 0).  SPC_V2_K1 / SPC_V2_K3 = "cb,block" force a variant.
-V2Choice v2_pick(const char *env, int pass, int64_t n_cols, int nG, int nL)
+// The second-generation variants are NOT selected by default.  Round 2 first measured them 2-7 % ahead at some sizes
+// (profiles/r02_kbench_variants.log), but those A/Bs ran inside the GPU's clock ramp (short timed loops after an idle
+// gap, the first variant of a process measured coldest); re-measured with pre-heated clocks the first-generation kernels
+// are as fast or faster at every size from 2k to 348k columns (profiles/r02_kbench_variants_hot.log: K1 151.5 vs 159.4 us
+// at 35 718 columns, K3 138.9 vs 141.1).  They stay built, bit-checked by the tests and selectable for A/B runs:
+// SPC_V2_K1 / SPC_V2_K3 = "cb,block".
+V2Choice v2_pick(const char *env)
 {
     V2Choice c;
     if (env_pair(env, &c.cb, &c.block)) return c;
     c.cb = 0; c.block = 0;
-    if (nG == 91 && nL == 160) {
-        if (pass == 0 && n_cols >= 6000 && n_cols <= 100000) { c.cb = 2; c.block = 192; }
-        if (pass == 1 && n_cols >= 200000) { c.cb = 8; c.block = 512; }
-    }
     return c;
 }
 
@@ -1182,7 +1180,7 @@ template <typename T> int forward_impl(const spc_dims *d, const spc_forward_args
             if (geo != 0 && d->cols_per_block == 0 && env_int("SPC_V2", 1) &&
                 aligned16({a->U, a->V, a->T, a->SH, a->QL, a->QI, a->Pf, a->Zgfull, a->zf, a->zh, a->u_d, a->v_d, a->thl_d, a->qt_d,
                            a->ql_d, a->f_u, a->f_v, a->f_thl, a->f_qt, a->f_ql, a->ql_ref})) {
-                rc = dispatch_fwd_v2(d, p, wt, (hipStream_t)stream, v2_pick("SPC_V2_K1", 0, d->n_cols, d->nG, d->nL));
+                rc = dispatch_fwd_v2(d, p, wt, (hipStream_t)stream, v2_pick("SPC_V2_K1"));
                 if (rc <= 0) return rc;
                 fill(p);
             }
@@ -1261,7 +1259,7 @@ template <typename T> int backward_impl(const spc_dims *d, const spc_backward_ar
         if (!cons && geo != 0 && d->cols_per_block == 0 && env_int("SPC_V2", 1) &&
             aligned16({a->T, a->SH, a->QL, a->QI, a->U, a->V, a->A, a->Zf, a->Zgfull, a->zf, a->t_d, a->qt_d, a->ql_d, a->ql_ice_d,
                        a->u_d, a->v_d, a->f_T, a->f_SH, a->f_QL, a->f_QI, a->f_U, a->f_V, a->f_A})) {
-            rc = dispatch_bwd_v2(d, p, wt, (hipStream_t)stream, v2_pick("SPC_V2_K3", 1, d->n_cols, d->nG, d->nL));
+            rc = dispatch_bwd_v2(d, p, wt, (hipStream_t)stream, v2_pick("SPC_V2_K3"));
             if (rc <= 0) return rc;
             p.d = make_dims(d, cb);
         }

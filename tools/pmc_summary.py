@@ -45,7 +45,8 @@ def main():
             ks[k]["fetch_counter_over_true"] = ks[k]["FETCH_SIZE_KiB_avg"] * 1024 / copy_bytes
             ks[k]["write_counter_over_true"] = ks[k].get("WRITE_SIZE_KiB_avg", 0) * 1024 / copy_bytes
     res["calibration"] = {}
-    for k, calk in (("k_forward", "k_copy16"), ("k_backward", "k_copy8")):    # K1 (16 B/lane at config 3), K3 (8 B/lane)
+    # both first-generation kernels access 8 B per lane (PMC_CAL_K1=k_copy16 when a 16-B second-generation K1 is forced)
+    for k, calk in (("k_forward", os.environ.get("PMC_CAL_K1", "k_copy8")), ("k_backward", "k_copy8")):
         cal = ks.get(calk, {})
         fr, wr = cal.get("fetch_counter_over_true", 0.5), cal.get("write_counter_over_true", 1.0)
         res["calibration"][k] = {"pattern": calk, "fetch_counter_over_true": fr, "write_counter_over_true": wr}

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define SPC_ABI_VERSION 1
+#define SPC_ABI_VERSION 2
 
 typedef enum spc_status {
     SPC_OK = 0,
@@ -181,6 +181,8 @@ typedef struct spc_vnudge_args {
     const void *ql_ref;                /* [n][ktot] les.ql_ref (K1's ql_ref output)                           */
     void *beta, *a_add, *qt_std;       /* [n][ktot] outputs                                                   */
     int32_t *status;                   /* [n][ktot] output                                                    */
+    void *work;                        /* optional device scratch of work_bytes >= n*2*itot*jtot*ktot*8 (ABI 2): qt and  */
+    int64_t work_bytes;                /* qsat transposed to contiguous planes, 8x fewer memory requests; NULL = without */
 } spc_vnudge_args;
 
 int spc_variability_nudge_f64(const spc_vnudge_args *args, void *stream);

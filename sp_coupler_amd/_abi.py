@@ -6,7 +6,7 @@ The product path has NO CPU fallback: ``load_library()`` raises ``SpcLibraryErro
 import ctypes
 import os
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libspc_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
@@ -66,7 +66,8 @@ class DiagnosticsArgs(ctypes.Structure):
 
 class VnudgeArgs(ctypes.Structure):
     _fields_ = ([("n_cols", c_int64), ("itot", c_int32), ("jtot", c_int32), ("ktot", c_int32), ("constantT", c_int32)]
-                + _ptrs("qt", "qsat", "thl", "ql", "R", "ql_av", "qt_av", "presf", "ql_ref", "beta", "a_add", "qt_std", "status"))
+                + _ptrs("qt", "qsat", "thl", "ql", "R", "ql_av", "qt_av", "presf", "ql_ref", "beta", "a_add", "qt_std", "status", "work")
+                + [("work_bytes", c_int64)])
 
 
 #: every symbol include/spc.h declares: name -> (restype, argtypes)

@@ -735,6 +735,7 @@ template <typename T, int NG, int NL, int WT, int BLK = BLOCK> __global__ __laun
 #include "spc_v2.hpp"
 
 #include "spc_vnudge.hpp"
+#include "spc_vnudge2.hpp"
 
 // =================================================================================================
 // K4 backward, conservative coarsening: splib/spcpl.py:479-489 -> sputils.interp_c / integral
@@ -1353,6 +1354,15 @@ int spc_surface_fluxes_f32(int64_t n, const void *Ph_s, const void *T_s, const v
     return surface_impl<float>(n, Ph_s, T_s, QLflux, QIflux, SHflux, TSflux, wthl, wqt, stream);
 }
 
+// leaves of numpy's pairwise recursion over n elements (n <= 8192): the host-side twin of vn_build_tree's count
+static int vn_count_leaves(int n)
+{
+    if (n <= 128) return 1;
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return vn_count_leaves(n2) + vn_count_leaves(n - n2);
+}
+
 int spc_variability_nudge_f64(const spc_vnudge_args *a, void *stream)
 {
     if (!a) return fail(SPC_ERR_INVALID_ARGUMENT, "%sargs is NULL");
@@ -1363,13 +1373,60 @@ int spc_variability_nudge_f64(const spc_vnudge_args *a, void *stream)
     REQUIRE(a->ql_ref, "ql_ref"); REQUIRE(a->beta, "beta"); REQUIRE(a->a_add, "a_add"); REQUIRE(a->qt_std, "qt_std");
     REQUIRE(a->status, "status");
     if (a->constantT) { REQUIRE(a->thl, "thl (constantT)"); REQUIRE(a->ql, "ql (constantT)"); REQUIRE(a->presf, "presf (constantT)"); }
-    if (a->n_cols > 65535) return fail(SPC_ERR_UNSUPPORTED, "%svariability_nudge: more than 65535 columns per launch");
+    if (a->n_cols > 32767) return fail(SPC_ERR_UNSUPPORTED, "%svariability_nudge: more than 32767 columns per launch");
     VnP p;
     p.n_cols = a->n_cols; p.nij = a->itot * a->jtot; p.ktot = a->ktot; p.constantT = a->constantT; p.pad = 0;
     p.qsat = (const double *)a->qsat; p.R = (const double *)a->R; p.ql_av = (const double *)a->ql_av; p.qt_av = (const double *)a->qt_av;
     p.presf = (const double *)a->presf; p.ql_ref = (const double *)a->ql_ref; p.ql = (const double *)a->ql;
     p.qt = (double *)a->qt; p.thl = (double *)a->thl; p.beta = (double *)a->beta; p.a_add = (double *)a->a_add;
     p.qt_std = (double *)a->qt_std; p.status = a->status;
+    // Planes that fit the LDS (KT levels x nij x 16 B <= 150 KiB, KT a power of two <= 16; 64 x 64 planes: KT = 2)
+    // are solved there (spc_vnudge2.hpp); larger planes (> ~9 000 points) keep the sweeping kernel.  SPC_VN_LDS=0: A/B.
+    int kt = 16, log2_kt = 4;
+    const int cn = p.nij < 8192 ? p.nij : 8192, nleaf_max = p.nij > 8192 ? VN_MAXLEAF : vn_count_leaves(cn);
+    auto lds_need = [&](int t) { return (size_t)t * vn2_plane(p.nij) * 16 + (size_t)t * nleaf_max * 8 + VN2_THREADS * 12; };
+    while (kt > 1 && lds_need(kt) > (size_t)VN2_MAX_LDS) { kt >>= 1; --log2_kt; }
+    if (lds_need(kt) <= (size_t)VN2_MAX_LDS && env_int("SPC_VN_LDS", 1)) {
+        // many workgroups (more than two rounds of one per CU): half the levels and half the threads per workgroup where
+        // that lets TWO workgroups share a CU's LDS -- one's barriers and serial steps overlap the other's sums
+        int nthreads = VN2_THREADS;
+        const int pair = env_int("SPC_VN_PAIR", 1);       // 0 never, 1 by workgroup count, 2 always (tests)
+        if (kt > 1 && lds_need(kt / 2) <= (size_t)(78 * 1024) &&
+            (pair == 2 || (pair == 1 && a->n_cols * (int64_t)((a->ktot + kt - 1) / kt) > 512))) {
+            kt >>= 1; --log2_kt; nthreads = VN2_THREADS / 2;
+        }
+        Vn2P q = {};
+        q.p = p; q.kt = kt; q.log2_kt = log2_kt; q.nleaf_max = nleaf_max;
+        for (int shape = 0; shape < 2; ++shape) {
+            unsigned char ready[VN_MAXLEAF];
+            vn_build_tree(shape == 0 ? 8192 : (p.nij % 8192 ? p.nij % 8192 : 8192), q.tab.lo[shape], q.tab.n[shape], q.tab.pl[shape],
+                          q.tab.pr[shape], &q.tab.nleaf[shape]);
+            q.tab.nround[shape] = vn_build_rounds(q.tab.nleaf[shape], q.tab.pl[shape], q.tab.pr[shape], q.tab.rnd[shape], ready);
+        }
+        q.work = nullptr;
+        const int64_t work_need = a->n_cols * 2 * (int64_t)p.nij * a->ktot * 8;
+        if (a->work && a->work_bytes >= work_need && env_int("SPC_VN_TRANSPOSE", 1)) {
+            hipLaunchKernelGGL(k_vnudge_transpose, dim3((unsigned)((p.nij + 63) / 64), (unsigned)((a->ktot + 15) / 16), (unsigned)(a->n_cols * 2)),
+                               dim3(256), 0, (hipStream_t)stream, p, (double *)a->work);
+            int rct = launch_status("k_vnudge_transpose");
+            if (rct) return rct;
+            q.work = (const double *)a->work;
+        }
+        q.tiles = (a->ktot + kt - 1) / kt;
+        q.tg = 16 / kt;                                       // tiles that share the 128-B lines of 16 levels
+        q.gpc = (q.tiles + q.tg - 1) / q.tg;
+        q.groups = a->n_cols * q.gpc;
+        const size_t smem = lds_need(kt);
+        int rc = ensure_lds(k_vnudge_solve, smem, "variability_nudge");
+        if (rc) return rc;
+        const int64_t nblk = (q.groups + 7) / 8 * 8 * q.tg;
+        if (nblk > INT32_MAX) return fail(SPC_ERR_UNSUPPORTED, "%svariability_nudge: too many workgroups");
+        hipLaunchKernelGGL(k_vnudge_solve, dim3((unsigned)nblk), dim3(nthreads), smem, (hipStream_t)stream, q);
+        rc = launch_status("k_vnudge_solve");
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_vnudge_apply, dim3((unsigned)((a->ktot + 15) / 16), (unsigned)a->n_cols), dim3(256), 0, (hipStream_t)stream, p);
+        return launch_status("k_vnudge_apply");
+    }
     hipLaunchKernelGGL(k_vnudge, dim3((unsigned)((a->ktot + VN_KT - 1) / VN_KT), (unsigned)a->n_cols), dim3(64 * VN_WAVES), 0, (hipStream_t)stream, p);
     return launch_status("k_vnudge");
 }

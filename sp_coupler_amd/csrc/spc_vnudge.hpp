@@ -222,7 +222,7 @@ __device__ __forceinline__ int vn_brent_start(VnBrent &b, double xa, double xb, 
 // Flattens numpy's pairwise recursion over a chunk of cn <= 8192 elements: leaves (lo, n) in order, and the combine
 // program in post-order -- step t: slot[pl[t]] = slot[pl[t]] + slot[pr[t]] (node = left + right; a subtree's value
 // lives in the slot of its first leaf) -- so that the sum ends in slot 0.
-__device__ inline void vn_build_tree(int cn, unsigned short *lo, unsigned short *n, unsigned short *pl, unsigned short *pr, int *nleaf)
+__host__ __device__ inline void vn_build_tree(int cn, unsigned short *lo, unsigned short *n, unsigned short *pl, unsigned short *pr, int *nleaf)
 {
     int r_n[10], lslot[10], rslot[10], depth = 0, cur_lo = 0, cur_n = cn, li = 0, np = 0;
     bool has_left[10];

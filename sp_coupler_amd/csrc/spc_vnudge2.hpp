@@ -1,0 +1,430 @@
+// spc_vnudge2.hpp -- variability nudge with the planes resident in LDS (K6a solve + K6b apply / std).
+//
+// k_vnudge (spc_vnudge.hpp) re-reads a level's qt / qsat plane from memory for every evaluation of the root finder
+// (~30 sweeps per level: L2-resident for a few LES, HBM-bound for hundreds).  Here a workgroup owns KT levels of one
+// column, KT chosen so that their qt and qsat planes (KT x nij x 16 B) FIT THE CU's LDS (64 x 64 planes: KT = 2,
+// 128 KiB); it loads them once and runs every evaluation from LDS.  The 512 threads split into KT groups, one per level;
+// inside a group 8 consecutive lanes carry the 8 accumulators of ONE numpy pairwise leaf (<= 128 elements; lane j sums
+// elements j, j+8, ...) and combine them ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) by shuffles -- the order numpy uses -- so a
+// 4096-point plane is summed by 256 threads in 16 steps; the leaf sums are then combined in numpy's tree order by
+// dependency rounds (vn_build_rounds).  Root finder, branches and status bits are those of k_vnudge (scipy brentq
+// restated as a resumable step function, one evaluation per level and round).  The solve leaves beta / a and the
+// apply code in `status`; k_vnudge_apply (16 levels of one column per workgroup, coalesced rows streamed through an LDS
+// tile) then rewrites qt (thl with constantT) and takes qt.std(axis=(0,1)) in numpy's sequential order.
+// Bit-identical to k_vnudge and to the NumPy / SciPy oracle (tests/test_vnudge.py runs both paths).
+#pragma once
+
+constexpr int VN2_THREADS = 512;
+constexpr int VN2_MAX_LDS = 150 * 1024;           // planes + scratch per workgroup (of the CU's 160 KiB)
+enum { VN2_APPLY_MULT = 1 << 20, VN2_APPLY_ADD = 1 << 21, VN2_TOUCHED = 1 << 22, VN2_INTERNAL = 7 << 20 };
+
+// LDS position of plane element e: 8 doubles of skew per 128 elements, so that the 8 leaf groups of a wave (leaf starts
+// 128 elements = 1 KiB apart, i.e. on the SAME banks) read 8 different 64-B bank ranges (measured without it: 8 us per
+// evaluation round, LDS-conflict bound)
+__device__ __forceinline__ int vn2_pos(int e) { return e + ((e >> 7) << 3); }
+__host__ __device__ inline int vn2_plane(int nij) { return nij + ((nij >> 7) << 3) + 8; }
+
+// numpy's pairwise tree of the two chunk shapes (0 = a full 8192-element chunk, 1 = the last or only chunk), flattened
+// ON THE HOST (vn_build_tree walks a stack: in a kernel that stack is scratch memory, 90 us per workgroup) and handed to
+// the kernel in its argument block: leaves (lo, n), the post-order combine program slot[pl] += slot[pr], and the
+// dependency round of every step
+struct Vn2Tables {
+    unsigned short lo[2][VN_MAXLEAF], n[2][VN_MAXLEAF], pl[2][VN_MAXLEAF], pr[2][VN_MAXLEAF];
+    unsigned char rnd[2][VN_MAXLEAF];
+    int nleaf[2], nround[2];
+};
+
+struct Vn2P {
+    VnP p;
+    int kt, log2_kt, tiles, gpc, tg;    // levels per workgroup, tiles per column, line groups per column, tiles per group
+    int64_t groups;
+    int nleaf_max;
+    const double *work;                  // planes transposed to [col][field][k][ij] by k_vnudge_transpose, or NULL
+    Vn2Tables tab;
+};
+
+// K6t: qt and qsat of every column from the reference's [ij][k] order into contiguous planes [col][field][k][ij] of the
+// caller's workspace: the solve then fills its LDS with coalesced loads (128 KiB = 1 024 line requests) instead of one
+// 128-B line request per (ij, field) for 16 useful bytes (8 192 requests, 90 us per workgroup at the per-CU limit of
+// outstanding requests).  Tile = 64 rows x 16 levels through LDS; reads and writes are whole 128-B segments.
+__global__ __launch_bounds__(256) void k_vnudge_transpose(const VnP p, double *work)
+{
+    __shared__ double s_t[16][65];
+    const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
+    const int ij0 = blockIdx.x * 64, k0 = blockIdx.y * 16, nij = p.nij, ktot = p.ktot;
+    const int64_t col = blockIdx.z >> 1;
+    const int field = blockIdx.z & 1;
+    const double *const src = (field ? p.qsat : (const double *)p.qt) + col * (int64_t)nij * ktot;
+    double *const dst = work + (col * 2 + field) * (int64_t)ktot * nij;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int ij = ij0 + row + 16 * u, k = k0 + lane;
+        s_t[lane][row + 16 * u] = (ij < nij && k < ktot) ? src[(int64_t)ij * ktot + k] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k = k0 + row, ij = ij0 + lane + 16 * u;
+        if (ij < nij && k < ktot) dst[(int64_t)k * nij + ij] = s_t[row][lane + 16 * u];
+    }
+}
+
+// dependency rounds of the combine program of vn_build_tree: step t may run in round rnd[t] once both of its
+// operands are final (leaves are ready in round 0)
+__host__ __device__ inline int vn_build_rounds(int nleaf, const unsigned short *pl, const unsigned short *pr, unsigned char *rnd, unsigned char *ready)
+{
+    for (int i = 0; i < nleaf; ++i) ready[i] = 0;
+    int nr = 0;
+    for (int t = 0; t + 1 < nleaf; ++t) {
+        const int a = ready[pl[t]], b = ready[pr[t]], r = (a > b ? a : b) + 1;
+        rnd[t] = (unsigned char)r; ready[pl[t]] = (unsigned char)r;
+        if (r > nr) nr = r;
+    }
+    return nr;
+}
+
+__global__ __launch_bounds__(VN2_THREADS) void k_vnudge_solve(const Vn2P q)
+{
+    const VnP &p = q.p;
+    extern __shared__ __align__(16) unsigned char vn2_smem[];
+    __shared__ Vn2Tables s_tab;
+    __shared__ int s_flag[2];
+    unsigned short (&s_lo)[2][VN_MAXLEAF] = s_tab.lo, (&s_n)[2][VN_MAXLEAF] = s_tab.n, (&s_pl)[2][VN_MAXLEAF] = s_tab.pl, (&s_pr)[2][VN_MAXLEAF] = s_tab.pr;
+    unsigned char (&s_rnd)[2][VN_MAXLEAF] = s_tab.rnd;
+    int (&s_nleaf)[2] = s_tab.nleaf, (&s_nround)[2] = s_tab.nround;
+    __shared__ double s_x[16];
+    __shared__ int s_mode[16];
+
+    // ---- which (column, tile): the tiles that share 128-B lines of the [ij][k] rows run on ONE XCD (blockIdx % 8) ----
+    const unsigned b = blockIdx.x, xcd = b & 7u, slot = b >> 3;
+    const int tig = (int)(slot % (unsigned)q.tg);
+    const int64_t group = (int64_t)(slot / (unsigned)q.tg) * 8 + xcd;
+    if (group >= q.groups) return;
+    const int64_t col = group / q.gpc;
+    const int tile = (int)(group % q.gpc) * q.tg + tig;
+    if (tile >= q.tiles) return;
+
+    const int KT = q.kt, nij = p.nij, ktot = p.ktot, tid = threadIdx.x;
+    const int NT = blockDim.x;                               // 512, or 256 where two workgroups share a CU
+    const int TL = NT >> q.log2_kt;                          // threads per level
+    const int kl = tid / TL, tl = tid - kl * TL;              // my level of the tile, my index inside its group
+    const int grp = tl >> 3, acc = tl & 7, ngrp = TL >> 3;
+    const int k0 = tile * KT, k = k0 + kl;
+    const bool valid = k < ktot;
+    const bool own = tl == 0;
+    const int npl = vn2_plane(nij);                                            // skewed plane length
+    double *const s_qt = reinterpret_cast<double *>(vn2_smem);               // [KT][npl]
+    double *const s_qs = s_qt + (size_t)KT * npl;                              // [KT][npl]
+    double *const s_leaf = s_qs + (size_t)KT * npl;                            // [KT][nleaf_max]
+    double *const s_part = s_leaf + (size_t)KT * q.nleaf_max;                  // [VN2_THREADS] argmax values
+    int *const s_parti = reinterpret_cast<int *>(s_part + VN2_THREADS);        // [VN2_THREADS] argmax indices
+    double *const my_qt = s_qt + (size_t)kl * npl, *const my_qs = s_qs + (size_t)kl * npl, *const my_leaf = s_leaf + (size_t)kl * q.nleaf_max;
+
+    {   // the host-built tree tables: argument block -> LDS, one 4-byte word per lane
+        static_assert(sizeof(Vn2Tables) % 4 == 0, "Vn2Tables is copied by words");
+        const unsigned __attribute__((address_space(4))) *const src = (const unsigned __attribute__((address_space(4))) *)(
+            (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(Vn2P, tab));
+        unsigned *const dstw = reinterpret_cast<unsigned *>(&s_tab);
+        for (int i = threadIdx.x; i < (int)(sizeof(Vn2Tables) / 4); i += blockDim.x) dstw[i] = src[i];
+    }
+
+    // ---- planes -> LDS ---------------------------------------------------------------------------------------------------
+    if (q.work) {                                   // transposed workspace: every level's group streams its own planes
+        const int kq = valid ? k : ktot - 1;
+        const double *const wq = q.work + ((col * 2 + 0) * (int64_t)ktot + kq) * nij;
+        const double *const ws = q.work + ((col * 2 + 1) * (int64_t)ktot + kq) * nij;
+#pragma unroll 4
+        for (int ij = tl; ij < nij; ij += TL) {
+            my_qt[vn2_pos(ij)] = wq[ij];
+            my_qs[vn2_pos(ij)] = ws[ij];
+        }
+    } else {                                        // [ij][k] order: element e = (ij, level of the tile), levels fastest
+        const int64_t base = col * (int64_t)nij * ktot;
+        const int total = nij << q.log2_kt;
+#pragma unroll 8
+        for (int e = tid; e < total; e += NT) {
+            const int ij = e >> q.log2_kt, l = e & (KT - 1);
+            const int kq = (k0 + l) < ktot ? (k0 + l) : ktot - 1;
+            const int64_t g = base + (int64_t)ij * ktot + kq;
+            s_qt[(size_t)l * npl + vn2_pos(ij)] = p.qt[g];
+            s_qs[(size_t)l * npl + vn2_pos(ij)] = p.qsat[g];
+        }
+    }
+    const int kk = valid ? k : ktot - 1;
+    const int64_t lev = col * ktot + kk;
+    const double *const R = p.R + col * (int64_t)nij;
+    const double qt_av = p.qt_av[lev], ql_ref = p.ql_ref[lev], ql_av = p.ql_av[lev];
+
+    // ---- per-level state (lane 0 of each level's group) ----------------------------------------------------------------
+    int stage = VS_DONE, st = VN_NONE, err = 0, apply = 0;
+    bool touched = false, want_argmax = false;
+    double beta = 1.0, a = 0.0, f_lo = 0.0;
+    VnBrent br = {};
+    if (own) {
+        if (valid) {
+            if (ql_ref > 1e-9) { stage = VS_M0; touched = true; }                    // spcpl.py:665
+            else if (ql_av > ql_ref) { want_argmax = true; touched = true; }         // spcpl.py:679
+        }
+        s_mode[kl] = want_argmax ? 3 : 0;
+    }
+    if (tid == 0) s_flag[0] = 0;
+    __syncthreads();
+    if (own && want_argmax) atomicOr(&s_flag[0], 1);
+    __syncthreads();
+
+    // ---- "barely unsaturated" branch (spcpl.py:679-695): numpy.argmax(qt - qsat), first maximum, a NaN wins -------------
+    if (s_flag[0]) {
+        const int seg = (nij + TL - 1) / TL, lo = tl * seg, hi = (lo + seg) < nij ? (lo + seg) : nij;
+        double bv = 0.0;
+        int bi = -1;
+        if (s_mode[kl] == 3 && lo < hi) {
+            bi = lo; bv = my_qt[vn2_pos(lo)] - my_qs[vn2_pos(lo)];
+            for (int ij = lo + 1; ij < hi && !(bv != bv); ++ij) {
+                const double v = my_qt[vn2_pos(ij)] - my_qs[vn2_pos(ij)];
+                if (v > bv || v != v) { bv = v; bi = ij; }
+            }
+        }
+        s_part[tid] = bv; s_parti[tid] = bi;
+        __syncthreads();
+        if (own && want_argmax) {
+            double best = s_part[tid];
+            int idx = s_parti[tid];
+            for (int w = 1; w < TL && !(best != best); ++w) {
+                const int qi = s_parti[tid + w];
+                const double v = s_part[tid + w];
+                if (qi >= 0 && (v > best || v != v)) { best = v; idx = qi; }
+            }
+            beta = (my_qs[vn2_pos(idx)] - qt_av) / (my_qt[vn2_pos(idx)] - qt_av);  // spcpl.py:683
+            if (beta < 0) beta = 1.0;                                                // spcpl.py:692-695
+            st = VN_UNSAT;
+        }
+        __syncthreads();
+    }
+
+    auto after_beta = [&]() {                                                        // spcpl.py:703-725
+        if (beta >= 5.0) {
+            if (ql_ref > ql_av) { stage = VS_A0; }
+            else { st |= VN_ADD_SKIPPED; beta = 1.0; stage = VS_DONE; }
+        } else {
+            apply = 1; stage = VS_DONE;
+        }
+    };
+    if (own && want_argmax) after_beta();
+
+    // ---- root-finding rounds: one evaluation per level and round, every evaluation from LDS ------------------------------
+    // Two workgroup barriers per round: the level's first wave (CW lanes) combines the leaf sums in numpy's tree order by
+    // dependency rounds -- LDS operations of one wave execute in order, so no barrier between them -- and its lane 0 runs
+    // the level's state machine on the result.
+    const int CW = TL < 64 ? TL : 64;
+    volatile double *const vleaf = my_leaf;
+    for (;;) {
+        if (own) {
+            double x = 0.0;
+            int mode = 0;
+            switch (stage) {
+            case VS_M0: x = 0.0; mode = 1; break;
+            case VS_M1: x = 5.0; mode = 1; break;
+            case VS_MB: x = br.xcur; mode = 1; break;
+            case VS_A0: x = 0.0; mode = 2; break;
+            case VS_A1: x = 5.0; mode = 2; break;
+            case VS_AB: x = br.xcur; mode = 2; break;
+            default: break;
+            }
+            s_x[kl] = x; s_mode[kl] = mode;
+        }
+        __syncthreads();
+        int any = 0;
+        for (int l = 0; l < KT; ++l) any |= s_mode[l];
+        if (!any) break;
+        const double x = s_x[kl];
+        const int mode = s_mode[kl];
+        double total = 0.0;
+        for (int c0 = 0; c0 < nij; c0 += 8192) {                    // ndarray.sum(): 0.0 + chunk sums
+            const int cn = (nij - c0) < 8192 ? (nij - c0) : 8192;
+            const int shape = (c0 + cn < nij) ? 0 : 1;
+            const int nleaf = s_nleaf[shape];
+            // one leaf per 8-lane group: lane j carries numpy's accumulator r[j]; `term` reads the planes from LDS
+            auto leaves = [&](auto term) {
+                for (int li = grp; li < nleaf; li += ngrp) {        // uniform inside every 8-lane group
+                    const int lo = (int)s_lo[shape][li], n = (int)s_n[shape][li];
+                    double res;
+                    if (n < 8) {
+                        res = 0.0;
+                        if (acc == 0)
+                            for (int i = 0; i < n; ++i) res += term(lo + i);
+                    } else {
+                        const int cnt = n >> 3, n8 = cnt << 3;
+                        double r = term(lo + acc);
+#pragma unroll 4
+                        for (int i = 1; i < cnt; ++i) r += term(lo + 8 * i + acc);
+                        r = r + __shfl_down(r, 1, 8);               // lanes 0,2,4,6: r0+r1, r2+r3, r4+r5, r6+r7
+                        r = r + __shfl_down(r, 2, 8);               // lanes 0,4: (r0+r1)+(r2+r3), (r4+r5)+(r6+r7)
+                        r = r + __shfl_down(r, 4, 8);               // lane 0: the leaf's 8-accumulator sum
+                        res = r;
+                        if (acc == 0)
+                            for (int i = n8; i < n; ++i) res += term(lo + i);
+                    }
+                    if (acc == 0) my_leaf[li] = res;
+                }
+            };
+            if (mode == 1)
+                leaves([&](int ij) {
+                    const int e = vn2_pos(c0 + ij);
+                    const double t = ((x * (my_qt[e] - qt_av)) + qt_av) - my_qs[e];
+                    return (t >= 0.0 || t != t) ? t : 0.0;                           // numpy.maximum(t, 0)
+                });
+            else if (mode == 2)
+                leaves([&](int ij) {
+                    const int e = vn2_pos(c0 + ij);
+                    const double t = (my_qt[e] + (x * R[c0 + ij])) - my_qs[e];
+                    return (t >= 0.0 || t != t) ? t : 0.0;
+                });
+            __syncthreads();
+            if (tl < CW && mode != 0) {                             // numpy's tree, one dependency round at a time
+                const int nround = s_nround[shape];
+                for (int rd = 1; rd <= nround; ++rd) {
+                    for (int t = tl; t + 1 < nleaf; t += CW)
+                        if (s_rnd[shape][t] == rd) {
+                            const int l = s_pl[shape][t], r = s_pr[shape][t];
+                            vleaf[l] = vleaf[l] + vleaf[r];
+                        }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (own) total += vleaf[0];
+            }
+            if (c0 + 8192 < nij) __syncthreads();                   // the next chunk's leaves reuse the slots
+        }
+        if (own && stage != VS_DONE) {
+            const double f = total / (double)nij - ql_ref;                           // spcpl.py:646-648 / 653-656
+            double root = 0.0;
+            int rc = 0;
+            switch (stage) {
+            case VS_M0: f_lo = f; stage = VS_M1; break;
+            case VS_M1:
+                if (f_lo > 0 || f < 0) { beta = 5.0; st = VN_NO_BRACKET; after_beta(); }          // spcpl.py:669-673
+                else {
+                    st = VN_MULT;
+                    rc = vn_brent_start(br, 0.0, 5.0, f_lo, f, &root);
+                    if (rc == 0) stage = VS_MB;
+                    else { beta = root; err |= rc == 2 ? 1 : (rc == 3 ? 2 : 0); after_beta(); }
+                }
+                break;
+            case VS_MB:
+                br.fcur = f;
+                rc = vn_brent_next(br, &root);
+                if (rc != 0) { beta = root; err |= rc == 2 ? 1 : (rc == 3 ? 2 : 0); after_beta(); }
+                break;
+            case VS_A0: f_lo = f; stage = VS_A1; break;
+            case VS_A1:
+                st |= VN_ADD;
+                rc = vn_brent_start(br, 0.0, 5.0, f_lo, f, &root);
+                if (rc == 0) { stage = VS_AB; break; }
+                [[fallthrough]];
+            case VS_AB:
+                if (stage == VS_AB) { br.fcur = f; rc = vn_brent_next(br, &root); if (rc == 0) break; }
+                a = root; beta = 1.0; stage = VS_DONE;                               // spcpl.py:713-722
+                if (rc == 1) apply = 2; else err |= rc == 2 ? 1 : 2;
+                break;
+            default: break;
+            }
+        }
+    }
+
+    if (own && valid) {
+        p.beta[lev] = beta;
+        p.a_add[lev] = a;
+        p.status[lev] = st | ((err & 1) ? VN_ERR_SIGN : 0) | ((err & 2) ? VN_ERR_CONV : 0) |
+                        (apply == 1 ? VN2_APPLY_MULT : 0) | (apply == 2 ? VN2_APPLY_ADD : 0) | (touched ? VN2_TOUCHED : 0);
+    }
+}
+
+// K6b: qt (and thl with constantT) of every touched level, then qt.std(axis=(0, 1)) (spcpl.py:741): numpy reduces over
+// (i, j) with k as the inner loop, i.e. plain SEQUENTIAL sums in C order (mean = sum/N, then sum((x - mean)^2)/N, sqrt).
+// A workgroup owns 16 consecutive levels of one column (one 128-B line per (i, j) row) and streams the plane rows
+// through an LDS tile: all 256 threads load / update / store coalesced rows (16 lanes along k x 16 rows at a time, 8 rows
+// in flight per thread), then the 16 lanes of the first half-wave add the tile's rows to their level's sum IN ORDER from
+// LDS while the next tile's loads are in flight.  The mean's sum rides on the apply sweep; a second sweep re-reads the
+// updated qt for the variance.
+constexpr int VB_ROWS = 128;      // (i, j) rows per tile: 16 KiB of LDS, two tiles (ping-pong)
+__global__ __launch_bounds__(256) void k_vnudge_apply(const VnP p)
+{
+    __shared__ double s_tile[2][VB_ROWS][16];
+    __shared__ double s_mean[16];
+    constexpr int U = VB_ROWS / 16;                      // rows per thread and tile, all in flight together
+    const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
+    const int64_t col = blockIdx.y;
+    const int k = blockIdx.x * 16 + lane, nij = p.nij;
+    const bool valid = k < p.ktot;
+    const int kk = valid ? k : p.ktot - 1;
+    const int64_t lev = col * p.ktot + kk, ks = p.ktot, base = col * (int64_t)nij * ks + kk;
+    double *const qt = p.qt + base;
+    const double *const qsat = p.qsat + base, *const R = p.R + col * (int64_t)nij;
+    const int stv = p.status[lev];
+    const int ap = (stv & VN2_APPLY_MULT) ? 1 : ((stv & VN2_APPLY_ADD) ? 2 : 0);
+    const bool tch = (stv & VN2_TOUCHED) != 0;
+    const double coef = ap == 1 ? p.beta[lev] - 1 : p.a_add[lev], qt_av = p.qt_av[lev];
+    double *const thl = (p.constantT && tch) ? p.thl + base : nullptr;
+    const double *const ql = (p.constantT && tch) ? p.ql + base : nullptr;
+    double tc = 0.0;
+    if (thl) tc = (-K<double>::rlv) / (K<double>::cp * spc_pow(div_pref0(p.presf[lev]), K<double>::rd / K<double>::cp));   // spcpl.py:731
+    const int ntile = (nij + VB_ROWS - 1) / VB_ROWS;
+    auto load_tile = [&](int t, double (&v)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ij = t * VB_ROWS + row + 16 * u;
+            v[u] = (valid && ij < nij) ? qt[(int64_t)ij * ks] : 0.0;
+        }
+    };
+
+    // One barrier per tile: tile t goes to s_tile[t & 1], the loads of tile t + 1 are issued, and only then do the 16
+    // lanes of row 0 add tile t's rows IN ORDER (the other buffer was last read before the previous barrier).
+    double s = 0.0, v[U], w[U];
+    load_tile(0, v);
+    for (int t = 0; t < ntile; ++t) {
+        const int nr = (nij - t * VB_ROWS) < VB_ROWS ? (nij - t * VB_ROWS) : VB_ROWS;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = row + 16 * u, ij = t * VB_ROWS + r;
+            if (valid && r < nr) {
+                if (ap == 1) { v[u] = v[u] + coef * (v[u] - qt_av); qt[(int64_t)ij * ks] = v[u]; }          // spcpl.py:724-725
+                else if (ap == 2) { v[u] = v[u] + coef * R[ij]; qt[(int64_t)ij * ks] = v[u]; }             // spcpl.py:716-719
+                if (thl) {                                                                                  // spcpl.py:726-733
+                    const double tt = v[u] - qsat[(int64_t)ij * ks];
+                    const double ql_target = (tt >= 0.0 || tt != tt) ? tt : 0.0;
+                    thl[(int64_t)ij * ks] += tc * (ql_target - ql[(int64_t)ij * ks]);
+                }
+            }
+            s_tile[t & 1][r][lane] = v[u];
+        }
+        if (t + 1 < ntile) load_tile(t + 1, w);
+        __syncthreads();
+        if (row == 0) {
+#pragma unroll 8
+            for (int r = 0; r < nr; ++r) s += s_tile[t & 1][r][lane];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = w[u];
+    }
+    if (row == 0) s_mean[lane] = s / (double)nij;
+    __syncthreads();
+    const double mean = s_mean[lane];
+    double var = 0.0;
+    load_tile(0, v);                                      // this thread's own stores of sweep 1
+    for (int t = 0; t < ntile; ++t) {
+        const int nr = (nij - t * VB_ROWS) < VB_ROWS ? (nij - t * VB_ROWS) : VB_ROWS;
+#pragma unroll
+        for (int u = 0; u < U; ++u) s_tile[t & 1][row + 16 * u][lane] = v[u];
+        if (t + 1 < ntile) load_tile(t + 1, w);
+        __syncthreads();
+        if (row == 0) {
+#pragma unroll 8
+            for (int r = 0; r < nr; ++r) { const double dlt = s_tile[t & 1][r][lane] - mean; var += dlt * dlt; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = w[u];
+    }
+    if (row == 0 && valid) {
+        p.qt_std[lev] = sqrt(var / (double)nij);
+        p.status[lev] = stv & ~VN2_INTERNAL;
+    }
+}

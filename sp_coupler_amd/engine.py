@@ -116,6 +116,7 @@ class Engine:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.dtype = dtype
         sfx = _DTYPES[dtype]
+        self._vn_work = None                    # variability_nudge's transposed-plane scratch, grown on demand
         self._fwd = getattr(self.lib, "spc_forward_" + sfx)
         self._bwd = getattr(self.lib, "spc_backward_" + sfx)
         self._idx = getattr(self.lib, "spc_cloud_indices_" + sfx)
@@ -373,6 +374,12 @@ class Engine:
         res["status"] = self.empty(n, ktot, dtype=torch.int32)
         a.beta, a.a_add, a.qt_std, a.status = (res["beta"].data_ptr(), res["a"].data_ptr(), res["qt_std"].data_ptr(),
                                                res["status"].data_ptr())
+        # scratch for the transposed qt / qsat planes (include/spc.h: spc_vnudge_args.work), kept between calls
+        need = n * 2 * itot * jtot * ktot * 8
+        if self._vn_work is None or self._vn_work.numel() < need:
+            self._vn_work = None
+            self._vn_work = torch.empty(need, dtype=torch.uint8, device=self.device)
+        a.work, a.work_bytes = self._vn_work.data_ptr(), self._vn_work.numel()
         with torch.cuda.device(self.device):
             rc = self.lib.spc_variability_nudge_f64(ctypes.byref(a), _stream_ptr(stream, self.device))
         _abi.check(self.lib, rc)

@@ -34,7 +34,7 @@ def test_header_symbols_all_exported_and_bound(lib):
 
 
 def test_abi_version_and_error_text(lib):
-    assert lib.spc_abi_version() == _abi.ABI_VERSION == 1
+    assert lib.spc_abi_version() == _abi.ABI_VERSION == 2
     assert isinstance(lib.spc_last_error(), bytes)
 
 
@@ -44,7 +44,7 @@ def test_struct_layout_matches_c_compiler(tmp_path):
               ("spc_forward_args", _abi.ForwardArgs, ["U", "zf", "rain_last", "factor", "dt", "f_u", "idx", "Z0M", "wqt"]),
               ("spc_backward_args", _abi.BackwardArgs, ["T", "A_prof", "rhobf_d", "conservative", "factor", "dt", "f_T", "start_index"]),
               ("spc_diagnostics_args", _abi.DiagnosticsArgs, ["T", "zf", "Tv", "ql_water"]),
-              ("spc_vnudge_args", _abi.VnudgeArgs, ["n_cols", "itot", "ktot", "constantT", "qt", "R", "presf", "beta", "status"])]
+              ("spc_vnudge_args", _abi.VnudgeArgs, ["n_cols", "itot", "ktot", "constantT", "qt", "R", "presf", "beta", "status", "work", "work_bytes"])]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "spc.h"', 'int main(void){']
     for cname, _, fields in probes:
         lines.append('printf("%%zu\\n", sizeof(%s));' % cname)

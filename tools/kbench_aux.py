@@ -69,8 +69,8 @@ def main():
         def run():
             qt.copy_(qt0)
             eng.variability_nudge(qt, qsat, R, prof["ql_av"], prof["qt_av"], prof["ql_ref"])
-        t = timed(run, 5)
-        tc = timed(lambda: qt.copy_(qt0), 5)
+        t = timed(run, 20)
+        tc = timed(lambda: qt.copy_(qt0), 20)
         print("K6 variability nudge: %d LES of 64x64x160: %.0f us per launch (%.0f us of it the qt reset copy); "
               "the reference's brentq over NumPy: see tests" % (ncol, t, tc), flush=True)
 

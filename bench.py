@@ -437,6 +437,9 @@ def main():
         "config": {"workload": wtxt, "total_cols": total_cols, "n_cols_per_gpu": n_cols, "nG": nG, "nL": nL,
                    "rotate": rotate, "launches_per_step": 2, "parallelism": "columns sharded, no collective"},
         "backend": (args.backend if world > 1 else None),
+        "series_note": ("N = 1 runs config 3 (35 718 columns, the largest config BASELINE.json places on ONE GPU); N > 1 shard config 4 "
+                        "(348 528 columns) -- per-GPU launches of 174 264 / 87 132 / 43 566 columns, which run at a higher fraction of the "
+                        "roofline than config 3's (DESIGN.md section 4); config 4 on one GPU: --config 4"),
         "bytes_per_exchange": ab["exchange"],
         "hbm_frac_whole_step": value / world * ab["exchange"] / 1e9 / HBM_PEAK_GBS,
     }

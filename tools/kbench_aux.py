@@ -15,10 +15,13 @@ from sp_coupler_amd import synthetic  # noqa: E402
 from sp_coupler_amd.engine import Engine  # noqa: E402
 
 
-def timed(fn, iters):
-    for _ in range(3):
-        fn()
-    torch.cuda.synchronize()
+def timed(fn, iters, heat_ms=40.0):
+    import time
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < heat_ms:       # pre-heat past the clock ramp
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):

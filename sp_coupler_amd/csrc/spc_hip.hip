@@ -82,12 +82,18 @@ __device__ __forceinline__ double spc_pow(double x, double y) { return pow(x, y)
 //   product y log x keeps ~2^-57 relative accuracy, then exp of the reduced argument by its Taylor polynomial.
 // Measured on the host with the same IEEE operations against a long-double reference (2e7 points each exponent,
 // 1e-6 <= x <= 1.2 and the full exponent range): worst error 1.20 ulp, > 1 ulp in 1.4e-5 of the points (libm: 0.51 ulp).
-// Arguments outside the positive normal range (0, negative, subnormal, inf, NaN) take ocml's pow().
-__device__ __attribute__((noinline)) double spc_pow_slow(double x, double y) { return pow(x, y); }
-
+// Arguments outside (0, inf) get C99 pow()'s special values for a non-integer exponent, inline (0 -> inf or 0, inf -> 0 or
+// inf, negative -> NaN, -inf like +inf, NaN -> NaN); subnormal x goes through the same code (frexp normalises it).  No
+// call: an out-of-line ocml pow() made every K1 wave reserve ITS 100 registers (4 waves per SIMD instead of 6).
 __device__ __forceinline__ double spc_pow(double x, double y)
 {
-    if (!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308)) return spc_pow_slow(x, y);
+    if (!(x > 0.0 && x <= 1.7976931348623157e308)) {
+        if (x != x) return x;                                                      // NaN
+        const double big = __builtin_huge_val();
+        if (x == 0.0) return y < 0.0 ? big : 0.0;                                  // +-0 (not an odd integer y)
+        if (x == big || x == -big) return y < 0.0 ? 0.0 : big;                     // +-inf (not an odd integer y)
+        return __builtin_nan("");                                                  // negative finite x, non-integer y
+    }
     const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10, LOG2E = 1.44269504088896338700e+00;
     int e;
     double m = frexp(x, &e);                                         // [0.5, 1)
@@ -417,9 +423,17 @@ constexpr int cfloor_pow2(int n) { int p = 1; while (p * 2 <= n) p *= 2; return 
 #ifndef SPC_K3_WAVES
 #define SPC_K3_WAVES 1
 #endif
+#ifndef SPC_K1_NF        // K1: fields whose slope divisions are interleaved (5 = all at once)
+#define SPC_K1_NF 5
+#endif
 // BLK: workgroup size.  256 everywhere except the small-batch path (small_block()): there one workgroup of 512 / 1024
 // threads takes 2 / 4 columns, still one work item per thread, so that <= 256 workgroups cover the batch.
-template <typename T, bool FULL, int NG, int NL, int WT, int BLK = BLOCK>
+// PRE: issue the first work item's LES-side inputs and the per-column scalars in the prologue, so that ONE memory round
+//      trip covers them and the GCM slab: what a single-round launch (<= 1024 columns) needs.  Multi-round launches run
+//      with PRE = false: those ~20 registers are live across phase 1, whose pow() sets the kernel's register peak, and
+//      without them K1 fits 6 waves per SIMD instead of 5 (75 vs 94 VGPRs) -- K1's rate follows its resident waves
+//      (profiles/r02_occupancy_ab_hot.log): -7 % at 35 718 columns, +12 % at 1024 (profiles/r02_k1_occupancy6_ab.log).
+template <typename T, bool FULL, int NG, int NL, int WT, int BLK = BLOCK, bool PRE = true>
 __global__ __launch_bounds__(BLK, SPC_K1_WAVES) void k_forward(const FwdP<T, FULL> p)
 {
     const DimsP &d = p.d;
@@ -445,7 +459,8 @@ __global__ __launch_bounds__(BLK, SPC_K1_WAVES) void k_forward(const FwdP<T, FUL
     //      gains 4.5 % in K3.) ---------------------------------------------------------------------
     LesIn<T> pre2 = {};
     T pre_zgh = T(0), pre_zs = T(0);
-    if (tid < n2) {
+    if (!PRE) {
+    } else if (tid < n2) {
         const int c = tid / nL, l = tid - c * nL;
         pre2 = load_les<FwdP<T, FULL>, T>(p, l, (col0 + c) * pitchL + l);
     } else if (tid < nitems) {
@@ -456,7 +471,7 @@ __global__ __launch_bounds__(BLK, SPC_K1_WAVES) void k_forward(const FwdP<T, FUL
     }
     const int sc = BLK - 1 - tid;          // the LAST threads own the per-column scalars
     T sc_ps = T(0), sc_psd = T(0), sc_rain = T(0), sc_rl = T(0);
-    if (sc < ncol) {
+    if (PRE && sc < ncol) {
         sc_ps = ldg(&p.Ph[(col0 + sc) * pitchGh + nG]);                                   // spcpl.py:246
         sc_psd = ldg(&p.ps_d[col0 + sc]);
         if constexpr (FULL)
@@ -497,6 +512,11 @@ __global__ __launch_bounds__(BLK, SPC_K1_WAVES) void k_forward(const FwdP<T, FUL
     // ---- per-column scalars (inputs already in registers; stores drain behind phase 2) ----------
     if (sc < ncol) {
         const int64_t col = col0 + sc;
+        if (!PRE) {
+            sc_ps = ldg(&p.Ph[col * pitchGh + nG]); sc_psd = ldg(&p.ps_d[col]);             // spcpl.py:246
+            if constexpr (FULL)
+                if (OPT(rainrate)) { sc_rain = OPT(rain)[col]; sc_rl = OPT(rain_last)[col]; }
+        }
         stg<WT>(&p.f_ps[col], p.factor * (sc_ps - sc_psd) / p.dt);          // spcpl.py:332
         if constexpr (FULL) {
             if (OPT(ps)) OPT(ps)[col] = sc_ps;
@@ -518,15 +538,37 @@ __global__ __launch_bounds__(BLK, SPC_K1_WAVES) void k_forward(const FwdP<T, FUL
             const int c = e / nL, l = e - c * nL;
             const int64_t col = col0 + c, o = col * pitchL + l;
             const T *const s = lds + (size_t)c * 6 * nG;
-            const LesIn<T> in = (e == tid) ? pre2 : load_les<FwdP<T, FULL>, T>(p, l, o);
+            const LesIn<T> in = (PRE && e == tid) ? pre2 : load_les<FwdP<T, FULL>, T>(p, l, o);
             const Br<T> b = bracket2(s, nG, p2G, in.h);
-            T f0[5], f1[5], r[5];
+            T r[5];
+#if SPC_K1_NF == 5
+            {
+                T f0[5], f1[5];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                f0[k] = s[(k + 1) * nG + b.j0];
-                f1[k] = s[(k + 1) * nG + b.j1];
+                for (int k = 0; k < 5; ++k) {
+                    f0[k] = s[(k + 1) * nG + b.j0];
+                    f1[k] = s[(k + 1) * nG + b.j1];
+                }
+                interp_fields<5>(b, f0, f1, r);
             }
-            interp_fields<5>(b, f0, f1, r);
+#else
+            // fields in groups of SPC_K1_NF: fewer slope divisions interleaved, fewer live registers, more waves per SIMD
+#pragma unroll
+            for (int k0 = 0; k0 < 5; k0 += SPC_K1_NF) {
+                constexpr int G = SPC_K1_NF;
+                T f0[G], f1[G], rr[G];
+#pragma unroll
+                for (int k = 0; k < G; ++k) {
+                    const int kk = (k0 + k) < 5 ? (k0 + k) : 4;
+                    f0[k] = s[(kk + 1) * nG + b.j0];
+                    f1[k] = s[(kk + 1) * nG + b.j1];
+                }
+                interp_fields<G>(b, f0, f1, rr);
+#pragma unroll
+                for (int k = 0; k < G; ++k)
+                    if (k0 + k < 5) r[k0 + k] = rr[k];
+            }
+#endif
             const T thl = r[0], qt = r[1], ql = r[2], u = r[3], v = r[4];               // spcpl.py:224-228
             stg<WT>(&p.f_u[o], p.factor * (u - in.ud) / p.dt);               // spcpl.py:328
             stg<WT>(&p.f_v[o], p.factor * (v - in.vd) / p.dt);               // spcpl.py:329
@@ -543,8 +585,8 @@ __global__ __launch_bounds__(BLK, SPC_K1_WAVES) void k_forward(const FwdP<T, FUL
         } else {                                                                      // fused K2, spcpl.py:764
             const int ei = e - n2, c = ei / nG, m = ei - c * nG;
             const int64_t col = col0 + c, gh = col * pitchGh;
-            const T zgh = (e == tid) ? pre_zgh : ldg(&p.Zghalf[gh + (nG - 1 - m)]);
-            const T zs = (e == tid) ? pre_zs : ldg(&p.Zghalf[gh + nG]);
+            const T zgh = (PRE && e == tid) ? pre_zgh : ldg(&p.Zghalf[gh + (nG - 1 - m)]);
+            const T zs = (PRE && e == tid) ? pre_zs : ldg(&p.Zghalf[gh + nG]);
             const T Zh_k = div_grav(zgh - zs);                                        // spcpl.py:197
             const T *const zh = d.shared_grid ? lzh : lzh + (size_t)c * nL;
             p.idx[col * pitchG + m] = ss_right(zh, nL, Zh_k);
@@ -1148,9 +1190,18 @@ template <typename T> int forward_impl(const spc_dims *d, const spc_forward_args
     static const KLean klean1024[2][4] = {
         {k_forward<T, false, 0, 0, 0, 1024>, k_forward<T, false, 91, 160, 0, 1024>, k_forward<T, false, 137, 512, 0>, k_forward<T, false, 19, 160, 0, 1024>},
         {k_forward<T, false, 0, 0, 1, 1024>, k_forward<T, false, 91, 160, 1, 1024>, k_forward<T, false, 137, 512, 1>, k_forward<T, false, 19, 160, 1, 1024>}};
+    static const KLean klean6[2][4] = {     // PRE = false: 6 waves per SIMD, for launches of more than one round
+        {k_forward<T, false, 0, 0, 0, BLOCK, false>, k_forward<T, false, 91, 160, 0, BLOCK, false>, k_forward<T, false, 137, 512, 0, BLOCK, false>,
+         k_forward<T, false, 19, 160, 0, BLOCK, false>},
+        {k_forward<T, false, 0, 0, 1, BLOCK, false>, k_forward<T, false, 91, 160, 1, BLOCK, false>, k_forward<T, false, 137, 512, 1, BLOCK, false>,
+         k_forward<T, false, 19, 160, 1, BLOCK, false>}};
     // (the 137 <-> 512 slots hold the 256-thread kernels: 649 work items per column never qualify for small_block)
     const int sb = full ? 0 : small_block(d, d->nL + (with_idx ? d->nG : 0));
-    const int cb = sb ? sb : (full ? pick_cb(d, 0, with_idx, sizeof(T), kfull[0][geo]) : pick_cb(d, 0, with_idx, sizeof(T), klean[0][geo]));
+    // single-round launches keep the prologue prefetch (k_forward's PRE); SPC_K1_PRE=0/1 forces it off / on (A/B)
+    const int pre_env = env_int("SPC_K1_PRE", -1);
+    const bool pre = full || sb || (pre_env >= 0 ? pre_env != 0 : d->n_cols <= 1024);   // measured: PRE = false wins from 1100 columns
+    const KLean (&kl)[2][4] = pre ? klean : klean6;
+    const int cb = sb ? sb : (full ? pick_cb(d, 0, with_idx, sizeof(T), kfull[0][geo]) : pick_cb(d, 0, with_idx, sizeof(T), kl[0][geo]));
     const int wt = small_batch(d->n_cols * (int64_t)((6 * d->nL + 1) * sizeof(T) + (with_idx ? d->nG * 4 : 0)));
     size_t per_col, fixed;
     lds_elems(d, 0, with_idx, &per_col, &fixed);
@@ -1186,7 +1237,7 @@ template <typename T> int forward_impl(const spc_dims *d, const spc_forward_args
                 fill(p);
             }
         }
-        const KLean kern = sb == 4 ? klean1024[wt][geo] : (sb == 2 ? klean512[wt][geo] : klean[wt][geo]);
+        const KLean kern = sb == 4 ? klean1024[wt][geo] : (sb == 2 ? klean512[wt][geo] : kl[wt][geo]);
         if ((rc = ensure_lds(kern, smem, "forward"))) return rc;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(sb ? BLOCK * sb : BLOCK), smem, (hipStream_t)stream, p);
     }

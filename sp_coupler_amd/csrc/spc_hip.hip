@@ -1195,13 +1195,19 @@ template <typename T> int forward_impl(const spc_dims *d, const spc_forward_args
          k_forward<T, false, 19, 160, 0, BLOCK, false>},
         {k_forward<T, false, 0, 0, 1, BLOCK, false>, k_forward<T, false, 91, 160, 1, BLOCK, false>, k_forward<T, false, 137, 512, 1, BLOCK, false>,
          k_forward<T, false, 19, 160, 1, BLOCK, false>}};
+    static const KFull kfull6[2][4] = {
+        {k_forward<T, true, 0, 0, 0, BLOCK, false>, k_forward<T, true, 91, 160, 0, BLOCK, false>, k_forward<T, true, 137, 512, 0, BLOCK, false>,
+         k_forward<T, true, 19, 160, 0, BLOCK, false>},
+        {k_forward<T, true, 0, 0, 1, BLOCK, false>, k_forward<T, true, 91, 160, 1, BLOCK, false>, k_forward<T, true, 137, 512, 1, BLOCK, false>,
+         k_forward<T, true, 19, 160, 1, BLOCK, false>}};
     // (the 137 <-> 512 slots hold the 256-thread kernels: 649 work items per column never qualify for small_block)
     const int sb = full ? 0 : small_block(d, d->nL + (with_idx ? d->nG : 0));
     // single-round launches keep the prologue prefetch (k_forward's PRE); SPC_K1_PRE=0/1 forces it off / on (A/B)
     const int pre_env = env_int("SPC_K1_PRE", -1);
-    const bool pre = full || sb || (pre_env >= 0 ? pre_env != 0 : d->n_cols <= 1024);   // measured: PRE = false wins from 1100 columns
+    const bool pre = sb || (pre_env >= 0 ? pre_env != 0 : d->n_cols <= 1024);   // measured: PRE = false wins from 1100 columns
     const KLean (&kl)[2][4] = pre ? klean : klean6;
-    const int cb = sb ? sb : (full ? pick_cb(d, 0, with_idx, sizeof(T), kfull[0][geo]) : pick_cb(d, 0, with_idx, sizeof(T), kl[0][geo]));
+    const KFull (&kf)[2][4] = pre ? kfull : kfull6;
+    const int cb = sb ? sb : (full ? pick_cb(d, 0, with_idx, sizeof(T), kf[0][geo]) : pick_cb(d, 0, with_idx, sizeof(T), kl[0][geo]));
     const int wt = small_batch(d->n_cols * (int64_t)((6 * d->nL + 1) * sizeof(T) + (with_idx ? d->nG * 4 : 0)));
     size_t per_col, fixed;
     lds_elems(d, 0, with_idx, &per_col, &fixed);
@@ -1223,8 +1229,8 @@ template <typename T> int forward_impl(const spc_dims *d, const spc_forward_args
         fill(p);
         COP(rain); COP(rain_last); OOP(u); OOP(v); OOP(thl); OOP(qt); OOP(ps); OOP(Zf); OOP(Zh); OOP(rainrate);
         COP(Z0M); COP(Z0H); COP(QLflux); COP(QIflux); COP(SHflux); COP(TSflux); OOP(z0m); OOP(z0h); OOP(wthl); OOP(wqt);
-        if ((rc = ensure_lds(kfull[wt][geo], smem, "forward"))) return rc;
-        hipLaunchKernelGGL(kfull[wt][geo], dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
+        if ((rc = ensure_lds(kf[wt][geo], smem, "forward"))) return rc;
+        hipLaunchKernelGGL(kf[wt][geo], dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
     } else {
         FwdP<T, false> p;
         fill(p);

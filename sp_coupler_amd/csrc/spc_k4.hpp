@@ -11,6 +11,24 @@
 // Zf[nG] | Zh[nG+1] | X[7][nG] (layer means) | cell range ia, ib and edge pieces da, db per level [4][nG]; then zf and zh ([nL] each when shared, else [CB x nL] each).
 #pragma once
 
+// numpy's pairwise recursion with its depth fixed at compile time (no stack, no scratch memory): for the compile-time
+// level geometries a layer covers at most NL cells, and vn_pw_depth(NL) levels of splitting reach leaves of <= 128
+// elements for every n <= NL.  The run-time-geometry kernel keeps vn_npsum (explicit stack: 143 VGPRs, 3 waves per SIMD);
+// with this form K4 needs 76 VGPRs (6 waves per SIMD).
+constexpr int vn_pw_depth_of(int n) { return n <= 128 ? 0 : 1 + (vn_pw_depth_of(n / 2 - (n / 2) % 8) > vn_pw_depth_of(n - (n / 2 - (n / 2) % 8)) ? vn_pw_depth_of(n / 2 - (n / 2) % 8) : vn_pw_depth_of(n - (n / 2 - (n / 2) % 8))); }
+constexpr int vn_pw_depth(int nmax) { int d = 0; for (int n = 129; n <= nmax; ++n) { const int dn = vn_pw_depth_of(n); if (dn > d) d = dn; } return d; }
+template <int D, typename F> __device__ __forceinline__ auto vn_pw(const F &term, int lo, int n) -> decltype(term(0))
+{
+    if constexpr (D == 0) {
+        return vn_leaf(term, lo, n);
+    } else {
+        if (n <= 128) return vn_leaf(term, lo, n);
+        int n2 = n / 2;
+        n2 -= n2 % 8;
+        return vn_pw<D - 1>(term, lo, n2) + vn_pw<D - 1>(term, lo + n2, n - n2);
+    }
+}
+
 // NG / NL != 0: level counts fixed at compile time and contiguous columns (as k_forward / k_backward): the flat-index
 // divisions become multiply-shifts.
 template <typename T, int NG = 0, int NL = 0> __global__ __launch_bounds__(BLOCK) void k_backward_cons2(const BwdP<T> p)
@@ -112,7 +130,9 @@ template <typename T, int NG = 0, int NL = 0> __global__ __launch_bounds__(BLOCK
                 const T dz = z[ia + i + 1] - z[ia + i];
                 return wsum ? w[ia + i] * dz : (w[ia + i] * q(ia + i)) * dz;           // sputils.py:152 / 157
             };
-            const T S = cnt <= 128 ? T(0) + vn_leaf(term, 0, cnt) : vn_npsum(term, cnt);
+            T S;
+            if constexpr (NL != 0) S = T(0) + vn_pw<vn_pw_depth(NL)>(term, 0, cnt);         // cnt <= NL <= 8192: one chunk
+            else S = cnt <= 128 ? T(0) + vn_leaf(term, 0, cnt) : vn_npsum(term, cnt);
             const T ea = wsum ? w[ia] * da : (w[ia] * q(ia)) * da;                     // Sa / Swa, sputils.py:154,159
             const T eb = wsum ? w[ib] * db : (w[ib] * q(ib)) * db;                     // Sb / Swb
             const T num = (S - ea) - eb;

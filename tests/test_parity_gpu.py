@@ -596,3 +596,31 @@ def test_small_batch_large_workgroups_f32(eng):
             got = host((fp.outputs if k in fp.outputs else bp.outputs)[k]).astype(numpy.float64)
             scale = numpy.abs(ref[k]).max()
             assert numpy.abs(got - ref[k]).max() <= 2e-3 * scale, k
+
+
+@pytest.mark.parametrize("nG,nL", [(91, 160), (137, 512), (19, 160)])
+def test_conservative_coarsening_thick_layers_compile_time_geometries(eng, nG, nL):
+    """The compile-time-geometry K4 kernels sum a layer with numpy's pairwise recursion unrolled to a fixed depth
+    (spc_k4.hpp: vn_pw): an LES grid so fine that the lowest GCM layer covers ~90 % of its cells (> 128: the recursion
+    really splits) -- bit-exact against the plain-C oracle and, on a few columns, against NumPy itself."""
+    gcm, zf, zh, prof = synthetic.make_batch(16, nG, nL, seed=61 + nG)
+    ref0 = oracle_c.forward(gcm, zf, zh, prof, FACTOR, DT)
+    dz = float(numpy.median(ref0["Zh"][:, nG - 1])) / (0.9 * nL)          # lowest layer ~ 0.9 nL cells thick
+    zh = numpy.arange(nL, dtype=numpy.float64) * dz
+    zf = zh + 0.5 * dz
+    g, p = to_dev(gcm, eng.device), to_dev(prof, eng.device)
+    zf_d, zh_d = torch.from_numpy(zf).to(eng.device), torch.from_numpy(zh).to(eng.device)
+    got = eng.backward(g, zf_d, p, FACTOR, DT, Zf=None, conservative=True, zh=zh_d)
+    torch.cuda.synchronize()
+    ref_f = oracle_c.forward(gcm, zf, zh, prof, FACTOR, DT)
+    ref = oracle_c.backward(gcm, ref_f["Zf"], zf, prof, FACTOR, DT, conservative=True, zh=zh, Zh=ref_f["Zh"])
+    inside = ref_f["Zh"][:, nG - 1] <= zh[-1]
+    cells = numpy.searchsorted(zh, ref_f["Zh"][inside, nG - 1])
+    assert inside.sum() >= 3 and cells.max() > 128, (inside.sum(), cells.max() if inside.any() else None)
+    check_backward({k: host(v) for k, v in got.items()}, ref)
+    cols = numpy.nonzero(inside)[0][:3]
+    sub = {k: v[cols] for k, v in gcm.items()}
+    psub = {k: v[cols] for k, v in prof.items()}
+    ref_np = orc.backward_batched(sub, ref_f["Zf"][cols], psub, zf, FACTOR, DT, conservative=True, Zh=ref_f["Zh"][cols], zh=zh)
+    for k in ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V"):
+        assert_bits(k, host(got[k])[cols], ref_np[k])

@@ -315,7 +315,8 @@ def test_random_geometries_pitches_and_slab_sizes(eng):
     for trial in range(int(os.environ.get("SPC_FUZZ_TRIALS", "40"))):     # soak: SPC_FUZZ_TRIALS=500 SPC_FUZZ_SEED=n
         nG = int(rng.integers(1, 200))
         nL = int(rng.integers(1, 600))
-        n = int(rng.integers(1, 260)) if rng.uniform() < 0.7 else int(rng.integers(257, 1100))   # incl. the 512 / 1024-thread path
+        u = rng.uniform()     # mostly small; 257..1024: the 512 / 1024-thread path; above: the multi-round (PRE = false) kernels
+        n = int(rng.integers(1, 260)) if u < 0.6 else (int(rng.integers(257, 1100)) if u < 0.85 else int(rng.integers(1100, 5000)))
         cb = int(rng.choice([0, 1, 2, 3, 5, 8]))
         per_col = bool(rng.integers(0, 2)) and nL > 1
         pad = int(rng.choice([0, 0, 1, 7]))

@@ -649,7 +649,10 @@ template <typename T> __device__ __forceinline__ GcmIn<T> load_gcm(const BwdP<T>
     return r;
 }
 
-template <typename T, int NG, int NL, int WT, int BLK = BLOCK> __global__ __launch_bounds__(BLK, SPC_K3_WAVES) void k_backward(const BwdP<T> p)
+// PRE: the GCM-side inputs of a thread's first output level are loaded in the prologue (one memory round trip for a
+// single-round launch).  Without it K3 needs 60 instead of 78 VGPRs (8 waves per SIMD instead of 6): +4-7 % at 2-4 k
+// columns, nothing from 16 k on where K3 has saturated (profiles/r02_k3_pre_ab.log) -- used between 1 025 and 25 000 columns.
+template <typename T, int NG, int NL, int WT, int BLK = BLOCK, bool PRE = true> __global__ __launch_bounds__(BLK, SPC_K3_WAVES) void k_backward(const BwdP<T> p)
 {
     const DimsP &d = p.d;
     const int nG = NG ? NG : d.nG, nL = NL ? NL : d.nL, cb = d.cb, tid = threadIdx.x;
@@ -690,7 +693,7 @@ template <typename T, int NG, int NL, int WT, int BLK = BLOCK> __global__ __laun
     }
     if (d.shared_grid && tid < nL) hs0 = ldg(&p.zf[tid]);
     GcmIn<T> pre = {};
-    if (tid < n1) {
+    if (PRE && tid < n1) {
         const int c = tid / nG, k = tid - c * nG;
         const int64_t cg = (col0 + c) * pitchG;
         pre = load_gcm(p, cg + k, cg + (nG - 1 - k));
@@ -723,7 +726,7 @@ template <typename T, int NG, int NL, int WT, int BLK = BLOCK> __global__ __laun
         const T *const s = lds + (size_t)c * per_col;
         const T *const h = d.shared_grid ? lh : lh + (size_t)c * nL;
         const T *const Zf = s + 6 * nL;
-        const GcmIn<T> in = (e == tid) ? pre : load_gcm(p, g, cg + (nG - 1 - k));
+        const GcmIn<T> in = (PRE && e == tid) ? pre : load_gcm(p, g, cg + (nG - 1 - k));
         const T x = Zf[k];
         const int start_index = ss_left_neg(Zf, nG, h[nL - 1]);                        // spcpl.py:498
         // (the branch-light interp_fields<7> form was measured here too: no gain at 1024 columns and -12 % at
@@ -1299,13 +1302,19 @@ template <typename T> int backward_impl(const spc_dims *d, const spc_backward_ar
     static const KB kb1024[2][4] = {
         {k_backward<T, 0, 0, 0, 1024>, k_backward<T, 91, 160, 0, 1024>, k_backward<T, 137, 512, 0>, k_backward<T, 19, 160, 0, 1024>},
         {k_backward<T, 0, 0, 1, 1024>, k_backward<T, 91, 160, 1, 1024>, k_backward<T, 137, 512, 1>, k_backward<T, 19, 160, 1, 1024>}};
+    static const KB kb8[2][4] = {           // PRE = false: 8 waves per SIMD, for launches of a few rounds
+        {k_backward<T, 0, 0, 0, BLOCK, false>, k_backward<T, 91, 160, 0, BLOCK, false>, k_backward<T, 137, 512, 0, BLOCK, false>, k_backward<T, 19, 160, 0, BLOCK, false>},
+        {k_backward<T, 0, 0, 1, BLOCK, false>, k_backward<T, 91, 160, 1, BLOCK, false>, k_backward<T, 137, 512, 1, BLOCK, false>, k_backward<T, 19, 160, 1, BLOCK, false>}};
     const int sb = cons ? 0 : small_block(d, d->nL > d->nG ? d->nL : d->nG);
-    const int cb = sb ? sb : (cons ? pick_cb(d, 4, false, sizeof(T), kc[geo]) : pick_cb(d, 1, false, sizeof(T), kb[0][geo]));
+    const int pre_env = env_int("SPC_K3_PRE", -1);        // SPC_K3_PRE=0/1 forces the prologue prefetch off / on (A/B)
+    const bool pre = sb || (pre_env >= 0 ? pre_env != 0 : (d->n_cols <= 1024 || d->n_cols > 25000));
+    const KB (&kbs)[2][4] = pre ? kb : kb8;
+    const int cb = sb ? sb : (cons ? pick_cb(d, 4, false, sizeof(T), kc[geo]) : pick_cb(d, 1, false, sizeof(T), kbs[0][geo]));
     const int wt = small_batch(d->n_cols * (int64_t)(7 * d->nG * sizeof(T)));
     size_t per_col, fixed;
     lds_elems(d, cons ? 4 : 1, false, &per_col, &fixed);
     const size_t smem = (per_col * cb + fixed) * sizeof(T);
-    const KB kbw = sb == 4 ? kb1024[wt][geo] : (sb == 2 ? kb512[wt][geo] : kb[wt][geo]);
+    const KB kbw = sb == 4 ? kb1024[wt][geo] : (sb == 2 ? kb512[wt][geo] : kbs[wt][geo]);
     if ((rc = cons ? ensure_lds(kc[geo], smem, "backward (conservative)") : ensure_lds(kbw, smem, "backward"))) return rc;
     BwdP<T> p;
     p.d = make_dims(d, cb);

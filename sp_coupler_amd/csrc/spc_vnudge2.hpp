@@ -88,7 +88,7 @@ __global__ __launch_bounds__(VN2_THREADS) void k_vnudge_solve(const Vn2P q)
     const VnP &p = q.p;
     extern __shared__ __align__(16) unsigned char vn2_smem[];
     __shared__ Vn2Tables s_tab;
-    __shared__ int s_flag[2];
+    __shared__ int s_flag;
     unsigned short (&s_lo)[2][VN_MAXLEAF] = s_tab.lo, (&s_n)[2][VN_MAXLEAF] = s_tab.n, (&s_pl)[2][VN_MAXLEAF] = s_tab.pl, (&s_pr)[2][VN_MAXLEAF] = s_tab.pr;
     unsigned char (&s_rnd)[2][VN_MAXLEAF] = s_tab.rnd;
     int (&s_nleaf)[2] = s_tab.nleaf, (&s_nround)[2] = s_tab.nround;
@@ -167,13 +167,13 @@ __global__ __launch_bounds__(VN2_THREADS) void k_vnudge_solve(const Vn2P q)
         }
         s_mode[kl] = want_argmax ? 3 : 0;
     }
-    if (tid == 0) s_flag[0] = 0;
+    if (tid == 0) s_flag = 0;
     __syncthreads();
-    if (own && want_argmax) atomicOr(&s_flag[0], 1);
+    if (own && want_argmax) atomicOr(&s_flag, 1);
     __syncthreads();
 
     // ---- "barely unsaturated" branch (spcpl.py:679-695): numpy.argmax(qt - qsat), first maximum, a NaN wins -------------
-    if (s_flag[0]) {
+    if (s_flag) {
         const int seg = (nij + TL - 1) / TL, lo = tl * seg, hi = (lo + seg) < nij ? (lo + seg) : nij;
         double bv = 0.0;
         int bi = -1;

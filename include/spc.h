@@ -167,7 +167,9 @@ int spc_surface_fluxes_f32(int64_t n, const void *Ph_s, const void *T_s, const v
  *   bit 0 multiplicative root found, 1 "barely unsaturated" branch (spcpl.py:679-695), 2 additive root found,
  *   3 additive branch skipped (ql_ref <= ql_av), 4 no bracket -> beta_max; bit 8: brentq sign error (the reference
  *   raises ValueError there), bit 9: no convergence in 100 iterations (RuntimeError).
- * R: [n_cols][itot*jtot] the zero-mean Gaussian field of spcpl.py:620-621, drawn by the caller.                    */
+ * R: [n_cols][itot*jtot] the zero-mean Gaussian field of spcpl.py:620-621, drawn by the caller.  At most 32 767
+ * columns per call.  Planes of up to ~9 000 points are solved from the CU's LDS (three launches), larger ones by a
+ * kernel that sweeps them from memory; results are bit-identical either way.                                        */
 typedef struct spc_vnudge_args {
     int64_t n_cols;
     int32_t itot, jtot, ktot;

@@ -155,8 +155,20 @@ def verify(fplan, bplan, ref_f, ref_b, n_ref, factor, dt):
     if not err <= bound:
         bad.append("f_thl: max abs err %.3e > %.3e" % (err, bound))
     rel = err / float(numpy.abs(ref_f["f_thl"]).max())
+    # element-wise view of the same comparison: f_thl = factor (thl - thl_d) / dt cancels, so an element whose forcing is
+    # tiny carries the absolute error of thl (<= 8 ulp of ~300 K, / dt) on a small value; the two CPU oracles (NumPy / C)
+    # differ from each other by 4 ulp of thl (tests/test_oracle.py), so no tighter element-wise bar is definable
+    d = numpy.abs(F["f_thl"][:n_ref] - ref_f["f_thl"])
+    a = numpy.abs(ref_f["f_thl"])
+    nz = a > 0
+    erel = d[nz] / a[nz]
+    ew = {"max_abs_err": err, "abs_err_bound_8ulp_thl_over_dt": bound,
+          "max_rel_err_over_all_nonzero_elements": float(erel.max()) if erel.size else 0.0,
+          "fraction_of_elements_above_1e-10_relative": float((erel > 1e-10).mean()) if erel.size else 0.0,
+          "smallest_abs_f_thl_among_those": float(a[nz][erel > 1e-10].min()) if (erel > 1e-10).any() else None,
+          "max_rel_err_where_abs_f_thl_ge_1e-5": float((d[a >= 1e-5] / a[a >= 1e-5]).max()) if (a >= 1e-5).any() else None}
     return (not bad), {"columns_checked": int(n_ref), "bit_exact": "idx,f_u,f_v,f_qt,f_ql,ql_ref,f_ps,f_T,f_SH,f_QL,f_QI,f_U,f_V,f_A",
-                       "f_thl_max_rel_err": rel, "failures": bad}
+                       "f_thl_max_rel_err": rel, "f_thl_elementwise": ew, "failures": bad}
 
 
 def dropin_rate(eng, n_les=1024, steps=30, warmup=3, per_les_steps=3):
@@ -344,14 +356,15 @@ def main():
         k1_us, k3_us = wl.kernel_times(stream, sptr)
         # measured device-to-device copy rate of this box (16 B/lane streaming copy, 256 MiB, read + write bytes):
         # the practical HBM ceiling reported next to the 8 TB/s spec peak
+        from tools import spc_tools          # measurement instruments (tools/libspc_tools.so), not the product library
         src = torch.empty(1 << 28, dtype=torch.uint8, device=eng.device)
         dst = torch.empty_like(src)
         for _ in range(3):
-            eng.stream_copy(dst, src, stream)
+            spc_tools.stream_copy(dst, src, stream)
         c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         c0.record(stream)
         for _ in range(10):
-            eng.stream_copy(dst, src, stream)
+            spc_tools.stream_copy(dst, src, stream)
         c1.record(stream)
         torch.cuda.synchronize()
         copy_gbs = 2.0 * src.numel() * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define SPC_ABI_VERSION 2
+#define SPC_ABI_VERSION 3
 
 typedef enum spc_status {
     SPC_OK = 0,
@@ -193,19 +193,22 @@ int spc_variability_nudge_f64(const spc_vnudge_args *args, void *stream);
 int spc_abi_version(void);          /* == SPC_ABI_VERSION                                          */
 const char *spc_last_error(void);   /* text of the calling thread's last failure ("" if none)     */
 int spc_device_count(void);         /* number of visible HIP devices (0 if none / no driver)      */
-/* columns per workgroup the library would pick (pass 0 forward, 1 backward, 2 index, 3 diag, 4 conservative) */
+/* columns per workgroup the library would pick (pass 0 forward [lean, fused index map], 1 backward, 2 index, 3 diag,
+ * 4 conservative backward): the `cb` of spc_describe_launch */
 int spc_pick_cols_per_block(const spc_dims *dims, int pass);
-/* Measured device-to-device copy rate helper for roofline reporting: copies `bytes` from src to
- * dst with a 16 B/lane streaming kernel on `stream`.                                              */
-int spc_stream_copy(void *dst, const void *src, int64_t bytes, void *stream);
-/* The same with 8 B/lane accesses (the access width of the coupling kernels): calibrates the HBM
- * PMC counters on a known byte count in this path's own access pattern.                           */
-int spc_stream_copy_f64(void *dst, const void *src, int64_t bytes, void *stream);
-
-/* Bandwidth probe for roofline reporting (tools/bwprobe.py): n_read read streams and n_write write streams of
- * bytes_per_stream bytes each (stream r at src + r*bytes_per_stream, w at dst + w*bytes_per_stream), 16 B/lane,
- * `grid` workgroups of 256 threads.  Instantiated mixes: 1:1, 1:0, 0:1, 2:1, 4:2, 8:0, 0:7, 14:7, 16:7.      */
-int spc_stream_probe(int n_read, int n_write, void *dst, const void *src, int64_t bytes_per_stream, int grid, void *stream);
+/* WHICH kernel instantiation, slab size and grid the library launches for this batch, as text, e.g.
+ *   "k_forward<f64,lean,91,160,wt=1,blk=1024,pre=1> cb=4 grid=256 block=1024 lds=17472"
+ * (template arguments: element type, lean / full output set, compile-time level counts [0,0 = run-time geometry],
+ *  write-through stores, workgroup size, prologue prefetch).  pass as above; flags (pass 0 only): bit 0 = the index
+ * map is fused (idx != NULL), bit 1 = FULL variant (any optional output or surface coupling requested); elem_size 8
+ * (f64) or 4 (f32).  The text comes from the very function the launchers use to choose, so a test can walk the
+ * dispatch table and require that every instantiation it reaches is bit-checked (tests/test_dispatch_gpu.py).
+ * Writes at most buflen-1 characters + NUL; returns the length of the full text or a negative spc_status. */
+int spc_describe_launch(const spc_dims *dims, int pass, int flags, int elem_size, char *buf, int buflen);
+/* Bytes of spc_vnudge_args.work the LDS path of spc_variability_nudge_f64 wants for these extents
+ * (n_cols*2*itot*jtot*ktot*8), or 0 when the planes do not fit the LDS and the sweeping kernel -- which uses no
+ * workspace -- runs; negative spc_status on bad extents. */
+int64_t spc_vnudge_workspace_bytes(int64_t n_cols, int32_t itot, int32_t jtot, int32_t ktot);
 
 #ifdef __cplusplus
 }

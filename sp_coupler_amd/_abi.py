@@ -6,7 +6,7 @@ The product path has NO CPU fallback: ``load_library()`` raises ``SpcLibraryErro
 import ctypes
 import os
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libspc_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
@@ -87,9 +87,9 @@ PROTOTYPES = {
     "spc_last_error": (ctypes.c_char_p, []),
     "spc_device_count": (ctypes.c_int, []),
     "spc_pick_cols_per_block": (ctypes.c_int, [ctypes.POINTER(Dims), ctypes.c_int]),
-    "spc_stream_copy": (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
-    "spc_stream_copy_f64": (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
-    "spc_stream_probe": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, c_int64, ctypes.c_int, c_void_p]),
+    "spc_describe_launch": (ctypes.c_int, [ctypes.POINTER(Dims), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p,
+                                           ctypes.c_int]),
+    "spc_vnudge_workspace_bytes": (c_int64, [c_int64, c_int32, c_int32, c_int32]),
 }
 
 _lib = None
@@ -126,6 +126,15 @@ def load_library(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+def describe_launch(lib, dims, pass_, flags=1, elem_size=8):
+    """text of spc_describe_launch (include/spc.h): the kernel instantiation + launch shape chosen for ``dims``"""
+    buf = ctypes.create_string_buffer(256)
+    rc = lib.spc_describe_launch(ctypes.byref(dims), pass_, flags, elem_size, buf, len(buf))
+    if rc < 0:
+        check(lib, rc)
+    return buf.value.decode()
 
 
 def check(lib, rc):

@@ -777,8 +777,6 @@ template <typename T, int NG, int NL, int WT, int BLK = BLOCK, bool PRE = true> 
     }
 }
 
-#include "spc_v2.hpp"
-
 #include "spc_vnudge.hpp"
 #include "spc_vnudge2.hpp"
 
@@ -863,43 +861,6 @@ __global__ __launch_bounds__(BLOCK) void k_surface(int64_t n, const T *Ph_s, con
         wqt[i] = -(QLflux[i] + QIflux[i] + SHflux[i]) / rho;                           // spcpl.py:159
         wthl[i] = -TSflux[i] * spc_pow(div_pref0(ps), (-K<T>::rd) / K<T>::cp) / (K<T>::cp * rho);   // spcpl.py:161
     }
-}
-
-// 16 B/lane streaming copy: the measured-bandwidth yardstick reported beside the roofline (1:1 read/write;
-// a 4x-unrolled non-temporal variant measured no better: 4.4-5.1 vs 5.0-5.1 TB/s read+write).
-__global__ __launch_bounds__(BLOCK) void k_copy16(uint4 *dst, const uint4 *src, int64_t n16)
-{
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n16; i += (int64_t)gridDim.x * BLOCK)
-        dst[i] = src[i];
-}
-
-// Bandwidth probes (tools/bwprobe.py): what this box's HBM delivers for a pure read, a pure write and a
-// read:write mix in MANY concurrent streams like the coupling kernels' (NS separate arrays advancing together),
-// so that the kernels' achieved GB/s can be set against the ceiling of their own access pattern.
-// mode 0: copy, 1: read only (sum), 2: write only; NR read streams + NW write streams of `n16` uint4 each.
-template <int NR, int NW, int PB = BLOCK>
-__global__ __launch_bounds__(PB) void k_probe(uint4 *dst, const uint4 *src, int64_t n16, int64_t stride16, unsigned *sink)
-{
-    unsigned acc = 0;
-    for (int64_t i = (int64_t)blockIdx.x * PB + threadIdx.x; i < n16; i += (int64_t)gridDim.x * PB) {
-        uint4 v[NR > 0 ? NR : 1];
-#pragma unroll
-        for (int r = 0; r < NR; ++r) v[r] = src[r * stride16 + i];
-        uint4 w = {1u, 2u, 3u, (unsigned)i};
-#pragma unroll
-        for (int r = 0; r < NR; ++r) { w.x ^= v[r].x; w.y += v[r].y; w.z ^= v[r].z; w.w += v[r].w; }
-#pragma unroll
-        for (int q = 0; q < NW; ++q) dst[q * stride16 + i] = w;
-        if (NW == 0) acc += w.x + w.y + w.z + w.w;
-    }
-    if (NW == 0 && acc == 0x12345678u) *sink = acc;      // keeps the loads alive; practically never true
-}
-
-// 8 B/lane streaming copy: the access width of the coupling kernels (PMC calibration, tools/pmc_summary.py)
-__global__ __launch_bounds__(BLOCK) void k_copy8(double *dst, const double *src, int64_t n8)
-{
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n8; i += (int64_t)gridDim.x * BLOCK)
-        dst[i] = src[i];
 }
 
 // ---- host side --------------------------------------------------------------------------------
@@ -1047,26 +1008,10 @@ int launch_status(const char *what)
 #define REQUIRE(ptr, name) \
     if (!(ptr)) return fail(SPC_ERR_INVALID_ARGUMENT, "required pointer %s is NULL", name)
 
-// ---- second-generation kernels (spc_v2.hpp): fp64, compile-time geometry, lean outputs -------------------
-// SPC_V2=0 disables them (A/B against the first-generation kernels); SPC_V2_K1 / SPC_V2_K3 = "cb,block" pick a
-// specific instantiated variant; SPC_V2_REMAP=0/1 overrides the XCD-contiguous slab mapping.
 int env_int(const char *name, int dflt)
 {
     const char *e = getenv(name);
     return e ? atoi(e) : dflt;
-}
-
-bool env_pair(const char *name, int *a, int *b)
-{
-    const char *e = getenv(name);
-    return e && sscanf(e, "%d,%d", a, b) == 2;
-}
-
-bool aligned16(std::initializer_list<const void *> ptrs)
-{
-    for (const void *q : ptrs)
-        if (((uintptr_t)q & 15u) != 0) return false;
-    return true;
 }
 
 // Small batches run ONE round of workgroups and are bound by latency, not bandwidth: there fewer, larger workgroups
@@ -1082,77 +1027,73 @@ int small_block(const spc_dims *d, int items_per_col)
     return d->n_cols <= 512 ? 2 : 4;
 }
 
-struct V2Choice { int cb, block; };
+// ---- launch choice ---------------------------------------------------------------------------------------------
+// WHICH instantiation runs, and in what shape, is decided in ONE place per pass (choose_fwd / choose_bwd); the
+// launchers and spc_describe_launch (include/spc.h) both call it, so a test can walk the dispatch table and assert
+// that every instantiation it can reach has been bit-checked (tests/test_dispatch_gpu.py).
+struct Choice {
+    const char *kernel;
+    int elem, full, idx, geo, wt, blk, pre, cb;
+    unsigned grid;
+    size_t smem;
+};
 
-// The second-generation variants are NOT selected by default.  Round 2 first measured them 2-7 % ahead at some sizes
-// (profiles/r02_kbench_variants.log), but those A/Bs ran inside the GPU's clock ramp (short timed loops after an idle
-// gap, the first variant of a process measured coldest); re-measured with pre-heated clocks the first-generation kernels
-// are as fast or faster at every size from 2k to 348k columns (profiles/r02_kbench_variants_hot.log: K1 151.5 vs 159.4 us
-// at 35 718 columns, K3 138.9 vs 141.1).  They stay built, bit-checked by the tests and selectable for A/B runs:
-// SPC_V2_K1 / SPC_V2_K3 = "cb,block".
-V2Choice v2_pick(const char *env)
+constexpr int GEO_NG[4] = {0, 91, 137, 19}, GEO_NL[4] = {0, 160, 512, 160};
+
+template <typename T> using KLean = void (*)(const FwdP<T, false>);
+template <typename T> using KFull = void (*)(const FwdP<T, true>);
+template <typename T> using KBwd = void (*)(const BwdP<T>);
+
+#define SPC_FWD_ROW(FULL_, WT_, BLK_, PRE_)                                                                          \
+    {k_forward<T, FULL_, 0, 0, WT_, BLK_, PRE_>, k_forward<T, FULL_, 91, 160, WT_, BLK_, PRE_>,                      \
+     k_forward<T, FULL_, 137, 512, WT_, BLK_, PRE_>, k_forward<T, FULL_, 19, 160, WT_, BLK_, PRE_>}
+// 512- / 1024-thread workgroups (small_block): one round of <= 1024 columns of <= 256 work items each, i.e. always
+// write-through and never 137 <-> 512 (649 work items per column): only those instantiations exist
+#define SPC_FWD_ROW_BIG(BLK_)                                                                                        \
+    {k_forward<T, false, 0, 0, 1, BLK_, true>, k_forward<T, false, 91, 160, 1, BLK_, true>, nullptr,                 \
+     k_forward<T, false, 19, 160, 1, BLK_, true>}
+
+// lean forward kernel of (geometry, write-through, workgroup size, prologue prefetch); nullptr = not instantiated
+template <typename T> KLean<T> fwd_lean_kernel(int geo, int wt, int blk, int pre)
 {
-    V2Choice c;
-    if (env_pair(env, &c.cb, &c.block)) return c;
-    c.cb = 0; c.block = 0;
-    return c;
+    static const KLean<T> k256[2][2][4] = {{SPC_FWD_ROW(false, 0, BLOCK, false), SPC_FWD_ROW(false, 1, BLOCK, false)},
+                                           {SPC_FWD_ROW(false, 0, BLOCK, true), SPC_FWD_ROW(false, 1, BLOCK, true)}};
+    static const KLean<T> k512[4] = SPC_FWD_ROW_BIG(512), k1024[4] = SPC_FWD_ROW_BIG(1024);
+    if (blk == BLOCK) return k256[pre][wt][geo];
+    if (!wt || !pre) return nullptr;
+    return blk == 512 ? k512[geo] : (blk == 1024 ? k1024[geo] : nullptr);
 }
 
-template <int NG, int NL, int CB, int BLOCK_>
-int launch_fwd_v2(const spc_dims *d, FwdP<double, false> &p, int wt, hipStream_t stream)
+template <typename T> KFull<T> fwd_full_kernel(int geo, int wt, int pre)
 {
-    const bool with_idx = p.idx != nullptr;
-    const size_t smem = ((size_t)CB * NG * 7 + (with_idx ? (d->les_grid_shared ? (size_t)NL : (size_t)CB * NL) : 0)) * sizeof(double);
-    p.d = make_dims(d, CB);
-    p.d.xcd_remap = env_int("SPC_V2_REMAP", 1);
-    const unsigned grid = (unsigned)((d->n_cols + CB - 1) / CB);
-    // store / load policy: write-through for small launches, else non-temporal streaming (SPC_V2_NT=0: plain)
-    const int mode = wt ? 1 : (env_int("SPC_V2_NT", 1) ? 2 : 0);
-    auto kern = mode == 1 ? k_forward_v2<NG, NL, CB, BLOCK_, 1> : (mode == 2 ? k_forward_v2<NG, NL, CB, BLOCK_, 2> : k_forward_v2<NG, NL, CB, BLOCK_, 0>);
-    int rc = ensure_lds(kern, smem, "forward");
-    if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK_), smem, stream, p);
-    return launch_status("k_forward_v2");
+    static const KFull<T> k[2][2][4] = {{SPC_FWD_ROW(true, 0, BLOCK, false), SPC_FWD_ROW(true, 1, BLOCK, false)},
+                                        {SPC_FWD_ROW(true, 0, BLOCK, true), SPC_FWD_ROW(true, 1, BLOCK, true)}};
+    return k[pre][wt][geo];
 }
+#undef SPC_FWD_ROW
+#undef SPC_FWD_ROW_BIG
 
-template <int NG, int NL, int CB, int BLOCK_>
-int launch_bwd_v2(const spc_dims *d, BwdP<double> &p, int wt, hipStream_t stream)
+template <typename T> int choose_fwd(const spc_dims *d, bool with_idx, bool full, Choice *c)
 {
-    const size_t smem = ((size_t)CB * NL * 6 + (size_t)CB * NG + (d->les_grid_shared ? (size_t)NL : (size_t)CB * NL)) * sizeof(double);
-    p.d = make_dims(d, CB);
-    p.d.xcd_remap = env_int("SPC_V2_REMAP", 1);
-    const unsigned grid = (unsigned)((d->n_cols + CB - 1) / CB);
-    const int mode = wt ? 1 : (env_int("SPC_V2_NT_K3", 0) ? 2 : 0);      // K3: non-temporal measured neutral to worse
-    auto kern = mode == 1 ? k_backward_v2<NG, NL, CB, BLOCK_, 1> : (mode == 2 ? k_backward_v2<NG, NL, CB, BLOCK_, 2> : k_backward_v2<NG, NL, CB, BLOCK_, 0>);
-    int rc = ensure_lds(kern, smem, "backward");
-    if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK_), smem, stream, p);
-    return launch_status("k_backward_v2");
-}
-
-// instantiated (geometry, slab, workgroup) variants; -1 = not available -> first-generation kernel
-#define SPC_V2_VARIANTS(X) \
-    X(91, 160, 2, 128) X(91, 160, 2, 192) X(91, 160, 4, 256) X(91, 160, 4, 320) X(91, 160, 8, 512) \
-    X(137, 512, 2, 512) X(137, 512, 2, 256) X(19, 160, 4, 256) X(19, 160, 4, 320)
-
-int dispatch_fwd_v2(const spc_dims *d, FwdP<double, false> &p, int wt, hipStream_t stream, V2Choice c)
-{
-    if (c.cb == 0) return 1;
-#define X(NG_, NL_, CB_, BL_) \
-    if (d->nG == NG_ && d->nL == NL_ && c.cb == CB_ && c.block == BL_) return launch_fwd_v2<NG_, NL_, CB_, BL_>(d, p, wt, stream);
-    SPC_V2_VARIANTS(X)
-#undef X
-    return 1;   // no such variant
-}
-
-int dispatch_bwd_v2(const spc_dims *d, BwdP<double> &p, int wt, hipStream_t stream, V2Choice c)
-{
-    if (c.cb == 0) return 1;
-#define X(NG_, NL_, CB_, BL_) \
-    if (d->nG == NG_ && d->nL == NL_ && c.cb == CB_ && c.block == BL_) return launch_bwd_v2<NG_, NL_, CB_, BL_>(d, p, wt, stream);
-    SPC_V2_VARIANTS(X)
-#undef X
-    return 1;
+    c->kernel = "k_forward"; c->elem = (int)sizeof(T); c->full = full; c->idx = with_idx;
+    c->geo = geometry_id(d);
+    c->wt = small_batch(d->n_cols * (int64_t)((6 * d->nL + 1) * sizeof(T) + (with_idx ? d->nG * 4 : 0)));
+    // (137 <-> 512 never qualifies for small_block: 649 work items per column; nor does a launch whose write-through
+    //  stores were switched off for an A/B run)
+    const int sb = (full || !c->wt) ? 0 : small_block(d, d->nL + (with_idx ? d->nG : 0));
+    // single-round launches keep the prologue prefetch (k_forward's PRE); SPC_K1_PRE=0/1 forces it off / on (A/B)
+    const int pre_env = env_int("SPC_K1_PRE", -1);
+    c->pre = (sb || (pre_env >= 0 ? pre_env != 0 : d->n_cols <= 1024)) ? 1 : 0;   // measured: PRE = false wins from 1100 columns
+    c->blk = sb ? BLOCK * sb : BLOCK;
+    if (full)
+        c->cb = pick_cb(d, 0, with_idx, sizeof(T), fwd_full_kernel<T>(c->geo, 0, c->pre));
+    else
+        c->cb = sb ? sb : pick_cb(d, 0, with_idx, sizeof(T), fwd_lean_kernel<T>(c->geo, 0, BLOCK, c->pre));
+    size_t per_col, fixed;
+    lds_elems(d, 0, with_idx, &per_col, &fixed);
+    c->smem = (per_col * c->cb + fixed) * sizeof(T);
+    c->grid = (unsigned)((d->n_cols + c->cb - 1) / c->cb);
+    return SPC_OK;
 }
 
 template <typename T> int forward_impl(const spc_dims *d, const spc_forward_args *a, void *stream)
@@ -1178,77 +1119,34 @@ template <typename T> int forward_impl(const spc_dims *d, const spc_forward_args
     }
     const bool with_idx = a->idx != nullptr;
     const bool full = a->u || a->v || a->thl || a->qt || a->ps || a->Zf || a->Zh || a->rainrate || a->wthl;
-    const int geo = geometry_id(d);
-    using KFull = void (*)(const FwdP<T, true>);
-    using KLean = void (*)(const FwdP<T, false>);
-    static const KFull kfull[2][4] = {
-        {k_forward<T, true, 0, 0, 0>, k_forward<T, true, 91, 160, 0>, k_forward<T, true, 137, 512, 0>, k_forward<T, true, 19, 160, 0>},
-        {k_forward<T, true, 0, 0, 1>, k_forward<T, true, 91, 160, 1>, k_forward<T, true, 137, 512, 1>, k_forward<T, true, 19, 160, 1>}};
-    static const KLean klean[2][4] = {
-        {k_forward<T, false, 0, 0, 0>, k_forward<T, false, 91, 160, 0>, k_forward<T, false, 137, 512, 0>, k_forward<T, false, 19, 160, 0>},
-        {k_forward<T, false, 0, 0, 1>, k_forward<T, false, 91, 160, 1>, k_forward<T, false, 137, 512, 1>, k_forward<T, false, 19, 160, 1>}};
-    static const KLean klean512[2][4] = {
-        {k_forward<T, false, 0, 0, 0, 512>, k_forward<T, false, 91, 160, 0, 512>, k_forward<T, false, 137, 512, 0>, k_forward<T, false, 19, 160, 0, 512>},
-        {k_forward<T, false, 0, 0, 1, 512>, k_forward<T, false, 91, 160, 1, 512>, k_forward<T, false, 137, 512, 1>, k_forward<T, false, 19, 160, 1, 512>}};
-    static const KLean klean1024[2][4] = {
-        {k_forward<T, false, 0, 0, 0, 1024>, k_forward<T, false, 91, 160, 0, 1024>, k_forward<T, false, 137, 512, 0>, k_forward<T, false, 19, 160, 0, 1024>},
-        {k_forward<T, false, 0, 0, 1, 1024>, k_forward<T, false, 91, 160, 1, 1024>, k_forward<T, false, 137, 512, 1>, k_forward<T, false, 19, 160, 1, 1024>}};
-    static const KLean klean6[2][4] = {     // PRE = false: 6 waves per SIMD, for launches of more than one round
-        {k_forward<T, false, 0, 0, 0, BLOCK, false>, k_forward<T, false, 91, 160, 0, BLOCK, false>, k_forward<T, false, 137, 512, 0, BLOCK, false>,
-         k_forward<T, false, 19, 160, 0, BLOCK, false>},
-        {k_forward<T, false, 0, 0, 1, BLOCK, false>, k_forward<T, false, 91, 160, 1, BLOCK, false>, k_forward<T, false, 137, 512, 1, BLOCK, false>,
-         k_forward<T, false, 19, 160, 1, BLOCK, false>}};
-    static const KFull kfull6[2][4] = {
-        {k_forward<T, true, 0, 0, 0, BLOCK, false>, k_forward<T, true, 91, 160, 0, BLOCK, false>, k_forward<T, true, 137, 512, 0, BLOCK, false>,
-         k_forward<T, true, 19, 160, 0, BLOCK, false>},
-        {k_forward<T, true, 0, 0, 1, BLOCK, false>, k_forward<T, true, 91, 160, 1, BLOCK, false>, k_forward<T, true, 137, 512, 1, BLOCK, false>,
-         k_forward<T, true, 19, 160, 1, BLOCK, false>}};
-    // (the 137 <-> 512 slots hold the 256-thread kernels: 649 work items per column never qualify for small_block)
-    const int sb = full ? 0 : small_block(d, d->nL + (with_idx ? d->nG : 0));
-    // single-round launches keep the prologue prefetch (k_forward's PRE); SPC_K1_PRE=0/1 forces it off / on (A/B)
-    const int pre_env = env_int("SPC_K1_PRE", -1);
-    const bool pre = sb || (pre_env >= 0 ? pre_env != 0 : d->n_cols <= 1024);   // measured: PRE = false wins from 1100 columns
-    const KLean (&kl)[2][4] = pre ? klean : klean6;
-    const KFull (&kf)[2][4] = pre ? kfull : kfull6;
-    const int cb = sb ? sb : (full ? pick_cb(d, 0, with_idx, sizeof(T), kf[0][geo]) : pick_cb(d, 0, with_idx, sizeof(T), kl[0][geo]));
-    const int wt = small_batch(d->n_cols * (int64_t)((6 * d->nL + 1) * sizeof(T) + (with_idx ? d->nG * 4 : 0)));
-    size_t per_col, fixed;
-    lds_elems(d, 0, with_idx, &per_col, &fixed);
-    const size_t smem = (per_col * cb + fixed) * sizeof(T);
+    Choice c;
+    if ((rc = choose_fwd<T>(d, with_idx, full, &c))) return rc;
 #define CP(f) p.f = (const T *)a->f
 #define OP(f) p.f = (T *)a->f
 #define COP(f) p.o.f = (const T *)a->f
 #define OOP(f) p.o.f = (T *)a->f
-    const unsigned grid = (unsigned)((d->n_cols + cb - 1) / cb);
     auto fill = [&](auto &p) {
-        p.d = make_dims(d, cb);
+        p.d = make_dims(d, c.cb);
         CP(U); CP(V); p.Tm = (const T *)a->T; CP(SH); CP(QL); CP(QI); CP(Pf); CP(Ph); CP(Zgfull); CP(Zghalf);
         CP(zf); CP(zh); CP(u_d); CP(v_d); CP(thl_d); CP(qt_d); CP(ql_d); CP(ps_d);
         p.factor = (T)a->factor; p.dt = (T)a->dt;
         OP(f_u); OP(f_v); OP(f_thl); OP(f_qt); OP(f_ql); OP(ql_ref); OP(f_ps); p.idx = a->idx;
     };
     if (full) {
+        const KFull<T> kern = fwd_full_kernel<T>(c.geo, c.wt, c.pre);
         FwdP<T, true> p;
         fill(p);
         COP(rain); COP(rain_last); OOP(u); OOP(v); OOP(thl); OOP(qt); OOP(ps); OOP(Zf); OOP(Zh); OOP(rainrate);
         COP(Z0M); COP(Z0H); COP(QLflux); COP(QIflux); COP(SHflux); COP(TSflux); OOP(z0m); OOP(z0h); OOP(wthl); OOP(wqt);
-        if ((rc = ensure_lds(kf[wt][geo], smem, "forward"))) return rc;
-        hipLaunchKernelGGL(kf[wt][geo], dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
+        if ((rc = ensure_lds(kern, c.smem, "forward"))) return rc;
+        hipLaunchKernelGGL(kern, dim3(c.grid), dim3(c.blk), c.smem, (hipStream_t)stream, p);
     } else {
+        const KLean<T> kern = fwd_lean_kernel<T>(c.geo, c.wt, c.blk, c.pre);
+        if (!kern) return fail(SPC_ERR_UNSUPPORTED, "%sforward: no kernel instantiated for this launch choice (internal)");
         FwdP<T, false> p;
         fill(p);
-        if constexpr (std::is_same<T, double>::value) {
-            if (geo != 0 && d->cols_per_block == 0 && env_int("SPC_V2", 1) &&
-                aligned16({a->U, a->V, a->T, a->SH, a->QL, a->QI, a->Pf, a->Zgfull, a->zf, a->zh, a->u_d, a->v_d, a->thl_d, a->qt_d,
-                           a->ql_d, a->f_u, a->f_v, a->f_thl, a->f_qt, a->f_ql, a->ql_ref})) {
-                rc = dispatch_fwd_v2(d, p, wt, (hipStream_t)stream, v2_pick("SPC_V2_K1"));
-                if (rc <= 0) return rc;
-                fill(p);
-            }
-        }
-        const KLean kern = sb == 4 ? klean1024[wt][geo] : (sb == 2 ? klean512[wt][geo] : kl[wt][geo]);
-        if ((rc = ensure_lds(kern, smem, "forward"))) return rc;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(sb ? BLOCK * sb : BLOCK), smem, (hipStream_t)stream, p);
+        if ((rc = ensure_lds(kern, c.smem, "forward"))) return rc;
+        hipLaunchKernelGGL(kern, dim3(c.grid), dim3(c.blk), c.smem, (hipStream_t)stream, p);
     }
     return launch_status("k_forward");
 }
@@ -1271,6 +1169,51 @@ int cloud_idx_impl(const spc_dims *d, const void *zh, const void *Zh, int32_t *i
     return launch_status("k_cloud_idx");
 }
 
+#define SPC_BWD_ROW(WT_, BLK_, PRE_)                                                                                 \
+    {k_backward<T, 0, 0, WT_, BLK_, PRE_>, k_backward<T, 91, 160, WT_, BLK_, PRE_>, k_backward<T, 137, 512, WT_, BLK_, PRE_>, \
+     k_backward<T, 19, 160, WT_, BLK_, PRE_>}
+#define SPC_BWD_ROW_BIG(BLK_)                                                                                        \
+    {k_backward<T, 0, 0, 1, BLK_, true>, k_backward<T, 91, 160, 1, BLK_, true>, nullptr, k_backward<T, 19, 160, 1, BLK_, true>}
+
+// K3 of (geometry, write-through, workgroup size, prologue prefetch); nullptr = not instantiated (see fwd_lean_kernel)
+template <typename T> KBwd<T> bwd_kernel(int geo, int wt, int blk, int pre)
+{
+    static const KBwd<T> k256[2][2][4] = {{SPC_BWD_ROW(0, BLOCK, false), SPC_BWD_ROW(1, BLOCK, false)},
+                                          {SPC_BWD_ROW(0, BLOCK, true), SPC_BWD_ROW(1, BLOCK, true)}};
+    static const KBwd<T> k512[4] = SPC_BWD_ROW_BIG(512), k1024[4] = SPC_BWD_ROW_BIG(1024);
+    if (blk == BLOCK) return k256[pre][wt][geo];
+    if (!wt || !pre) return nullptr;
+    return blk == 512 ? k512[geo] : (blk == 1024 ? k1024[geo] : nullptr);
+}
+#undef SPC_BWD_ROW
+#undef SPC_BWD_ROW_BIG
+
+template <typename T> KBwd<T> cons_kernel(int geo)
+{
+    static const KBwd<T> kc[4] = {k_backward_cons2<T, 0, 0>, k_backward_cons2<T, 91, 160>, k_backward_cons2<T, 137, 512>,
+                                  k_backward_cons2<T, 19, 160>};
+    return kc[geo];
+}
+
+template <typename T> int choose_bwd(const spc_dims *d, bool cons, Choice *c)
+{
+    c->kernel = cons ? "k_backward_cons2" : "k_backward"; c->elem = (int)sizeof(T); c->full = cons; c->idx = 0;
+    c->geo = geometry_id(d);
+    c->wt = cons ? 0 : small_batch(d->n_cols * (int64_t)(7 * d->nG * sizeof(T)));
+    const int sb = (cons || !c->wt) ? 0 : small_block(d, d->nL > d->nG ? d->nL : d->nG);
+    const int pre_env = env_int("SPC_K3_PRE", -1);        // SPC_K3_PRE=0/1 forces the prologue prefetch off / on (A/B)
+    // PRE = false (8 waves per SIMD) pays between one round of workgroups and saturation: 1 025 ... 25 000 columns
+    c->pre = (cons || sb || (pre_env >= 0 ? pre_env != 0 : (d->n_cols <= 1024 || d->n_cols > 25000))) ? 1 : 0;
+    c->blk = sb ? BLOCK * sb : BLOCK;
+    c->cb = sb ? sb : (cons ? pick_cb(d, 4, false, sizeof(T), cons_kernel<T>(c->geo))
+                            : pick_cb(d, 1, false, sizeof(T), bwd_kernel<T>(c->geo, 0, BLOCK, c->pre)));
+    size_t per_col, fixed;
+    lds_elems(d, cons ? 4 : 1, false, &per_col, &fixed);
+    c->smem = (per_col * c->cb + fixed) * sizeof(T);
+    c->grid = (unsigned)((d->n_cols + c->cb - 1) / c->cb);
+    return SPC_OK;
+}
+
 template <typename T> int backward_impl(const spc_dims *d, const spc_backward_args *a, void *stream)
 {
     int rc = validate(d);
@@ -1290,52 +1233,18 @@ template <typename T> int backward_impl(const spc_dims *d, const spc_backward_ar
         if (!a->Zh && !a->Zghalf) return fail(SPC_ERR_INVALID_ARGUMENT, "%sconservative: neither Zh nor Zghalf given");
         if (d->nL < 2) return fail(SPC_ERR_INVALID_ARGUMENT, "%sconservative coarsening needs nL >= 2");
     }
-    const int geo = geometry_id(d);
-    using KB = void (*)(const BwdP<T>);
-    static const KB kb[2][4] = {
-        {k_backward<T, 0, 0, 0>, k_backward<T, 91, 160, 0>, k_backward<T, 137, 512, 0>, k_backward<T, 19, 160, 0>},
-        {k_backward<T, 0, 0, 1>, k_backward<T, 91, 160, 1>, k_backward<T, 137, 512, 1>, k_backward<T, 19, 160, 1>}};
-    static const KB kc[4] = {k_backward_cons2<T, 0, 0>, k_backward_cons2<T, 91, 160>, k_backward_cons2<T, 137, 512>, k_backward_cons2<T, 19, 160>};
-    static const KB kb512[2][4] = {
-        {k_backward<T, 0, 0, 0, 512>, k_backward<T, 91, 160, 0, 512>, k_backward<T, 137, 512, 0>, k_backward<T, 19, 160, 0, 512>},
-        {k_backward<T, 0, 0, 1, 512>, k_backward<T, 91, 160, 1, 512>, k_backward<T, 137, 512, 1>, k_backward<T, 19, 160, 1, 512>}};
-    static const KB kb1024[2][4] = {
-        {k_backward<T, 0, 0, 0, 1024>, k_backward<T, 91, 160, 0, 1024>, k_backward<T, 137, 512, 0>, k_backward<T, 19, 160, 0, 1024>},
-        {k_backward<T, 0, 0, 1, 1024>, k_backward<T, 91, 160, 1, 1024>, k_backward<T, 137, 512, 1>, k_backward<T, 19, 160, 1, 1024>}};
-    static const KB kb8[2][4] = {           // PRE = false: 8 waves per SIMD, for launches of a few rounds
-        {k_backward<T, 0, 0, 0, BLOCK, false>, k_backward<T, 91, 160, 0, BLOCK, false>, k_backward<T, 137, 512, 0, BLOCK, false>, k_backward<T, 19, 160, 0, BLOCK, false>},
-        {k_backward<T, 0, 0, 1, BLOCK, false>, k_backward<T, 91, 160, 1, BLOCK, false>, k_backward<T, 137, 512, 1, BLOCK, false>, k_backward<T, 19, 160, 1, BLOCK, false>}};
-    const int sb = cons ? 0 : small_block(d, d->nL > d->nG ? d->nL : d->nG);
-    const int pre_env = env_int("SPC_K3_PRE", -1);        // SPC_K3_PRE=0/1 forces the prologue prefetch off / on (A/B)
-    const bool pre = sb || (pre_env >= 0 ? pre_env != 0 : (d->n_cols <= 1024 || d->n_cols > 25000));
-    const KB (&kbs)[2][4] = pre ? kb : kb8;
-    const int cb = sb ? sb : (cons ? pick_cb(d, 4, false, sizeof(T), kc[geo]) : pick_cb(d, 1, false, sizeof(T), kbs[0][geo]));
-    const int wt = small_batch(d->n_cols * (int64_t)(7 * d->nG * sizeof(T)));
-    size_t per_col, fixed;
-    lds_elems(d, cons ? 4 : 1, false, &per_col, &fixed);
-    const size_t smem = (per_col * cb + fixed) * sizeof(T);
-    const KB kbw = sb == 4 ? kb1024[wt][geo] : (sb == 2 ? kb512[wt][geo] : kbs[wt][geo]);
-    if ((rc = cons ? ensure_lds(kc[geo], smem, "backward (conservative)") : ensure_lds(kbw, smem, "backward"))) return rc;
+    Choice c;
+    if ((rc = choose_bwd<T>(d, cons, &c))) return rc;
+    const KBwd<T> kern = cons ? cons_kernel<T>(c.geo) : bwd_kernel<T>(c.geo, c.wt, c.blk, c.pre);
+    if (!kern) return fail(SPC_ERR_UNSUPPORTED, "%sbackward: no kernel instantiated for this launch choice (internal)");
+    if ((rc = ensure_lds(kern, c.smem, cons ? "backward (conservative)" : "backward"))) return rc;
     BwdP<T> p;
-    p.d = make_dims(d, cb);
+    p.d = make_dims(d, c.cb);
     p.Tm = (const T *)a->T; CP(SH); CP(QL); CP(QI); CP(U); CP(V); CP(A); CP(Zf); CP(Zgfull); CP(Zghalf); CP(zf);
     CP(t_d); CP(qt_d); CP(ql_d); CP(ql_ice_d); CP(u_d); CP(v_d); CP(A_prof); CP(zh); CP(Zh); CP(rhobf_d);
     p.factor = (T)a->factor; p.dt = (T)a->dt;
     OP(f_T); OP(f_SH); OP(f_QL); OP(f_QI); OP(f_U); OP(f_V); OP(f_A); p.start_index = a->start_index;
-    if constexpr (std::is_same<T, double>::value) {
-        if (!cons && geo != 0 && d->cols_per_block == 0 && env_int("SPC_V2", 1) &&
-            aligned16({a->T, a->SH, a->QL, a->QI, a->U, a->V, a->A, a->Zf, a->Zgfull, a->zf, a->t_d, a->qt_d, a->ql_d, a->ql_ice_d,
-                       a->u_d, a->v_d, a->f_T, a->f_SH, a->f_QL, a->f_QI, a->f_U, a->f_V, a->f_A})) {
-            rc = dispatch_bwd_v2(d, p, wt, (hipStream_t)stream, v2_pick("SPC_V2_K3"));
-            if (rc <= 0) return rc;
-            p.d = make_dims(d, cb);
-        }
-    }
-    const unsigned grid = (unsigned)((d->n_cols + cb - 1) / cb);
-    if (cons)
-        hipLaunchKernelGGL(kc[geo], dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL(kbw, dim3(grid), dim3(sb ? BLOCK * sb : BLOCK), smem, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3(c.grid), dim3(c.blk), c.smem, (hipStream_t)stream, p);
     return launch_status(cons ? "k_backward_cons" : "k_backward");
 }
 
@@ -1380,6 +1289,27 @@ int surface_impl(int64_t n, const void *Ph_s, const void *T_s, const void *QLflu
     hipLaunchKernelGGL(k_surface<T>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, n, (const T *)Ph_s, (const T *)T_s,
                        (const T *)QLflux, (const T *)QIflux, (const T *)SHflux, (const T *)TSflux, (T *)wthl, (T *)wqt);
     return launch_status("k_surface");
+}
+
+template <typename T> int describe_impl(const spc_dims *d, int pass, int flags, Choice *c)
+{
+    switch (pass) {
+    case 0: return choose_fwd<T>(d, (flags & 1) != 0, (flags & 2) != 0, c);
+    case 1: return choose_bwd<T>(d, false, c);
+    case 4: return choose_bwd<T>(d, true, c);
+    case 2:
+    case 3: {
+        c->kernel = pass == 2 ? "k_cloud_idx" : "k_diag"; c->elem = (int)sizeof(T); c->full = c->idx = c->geo = c->wt = c->pre = 0;
+        c->blk = BLOCK;
+        c->cb = pass == 2 ? pick_cb(d, 2, true, sizeof(T), k_cloud_idx<T>) : pick_cb(d, 3, false, sizeof(T), k_diag<T>);
+        size_t per_col, fixed;
+        lds_elems(d, pass, pass == 2, &per_col, &fixed);
+        c->smem = (per_col * c->cb + fixed) * sizeof(T);
+        c->grid = (unsigned)((d->n_cols + c->cb - 1) / c->cb);
+        return SPC_OK;
+    }
+    default: return fail(SPC_ERR_INVALID_ARGUMENT, "%spass must be 0..4");
+    }
 }
 
 }  // namespace
@@ -1429,6 +1359,33 @@ static int vn_count_leaves(int n)
     return vn_count_leaves(n2) + vn_count_leaves(n - n2);
 }
 
+// LDS bytes of the plane-resident solver (spc_vnudge2.hpp) with `t` levels per workgroup
+static size_t vn_lds_need(int nij, int nleaf_max, int t)
+{
+    return (size_t)t * vn2_plane(nij) * 16 + (size_t)t * nleaf_max * 8 + VN2_THREADS * 12;
+}
+
+// Planes that fit the LDS (KT levels x nij x 16 B <= 150 KiB, KT a power of two <= 16; 64 x 64 planes: KT = 2) are
+// solved there; larger planes (> ~9 000 points) keep the sweeping kernel.  SPC_VN_LDS=0: A/B.  Returns whether the LDS
+// path applies and, if so, the levels per workgroup and the leaf count of numpy's pairwise tree.
+static bool vn_lds_fit(int nij, int *kt_, int *log2_kt_, int *nleaf_max_)
+{
+    int kt = 16, log2_kt = 4;
+    const int cn = nij < 8192 ? nij : 8192, nleaf_max = nij > 8192 ? VN_MAXLEAF : vn_count_leaves(cn);
+    while (kt > 1 && vn_lds_need(nij, nleaf_max, kt) > (size_t)VN2_MAX_LDS) { kt >>= 1; --log2_kt; }
+    *kt_ = kt; *log2_kt_ = log2_kt; *nleaf_max_ = nleaf_max;
+    return vn_lds_need(nij, nleaf_max, kt) <= (size_t)VN2_MAX_LDS && env_int("SPC_VN_LDS", 1);
+}
+
+int64_t spc_vnudge_workspace_bytes(int64_t n_cols, int32_t itot, int32_t jtot, int32_t ktot)
+{
+    if (n_cols < 0 || itot < 1 || jtot < 1 || ktot < 1 || (int64_t)itot * jtot > INT32_MAX / 2)
+        return fail(SPC_ERR_INVALID_ARGUMENT, "%svariability_nudge: bad extents");
+    int kt, log2_kt, nleaf_max;
+    if (!vn_lds_fit(itot * jtot, &kt, &log2_kt, &nleaf_max) || !env_int("SPC_VN_TRANSPOSE", 1)) return 0;
+    return n_cols * 2 * (int64_t)itot * jtot * ktot * 8;
+}
+
 int spc_variability_nudge_f64(const spc_vnudge_args *a, void *stream)
 {
     if (!a) return fail(SPC_ERR_INVALID_ARGUMENT, "%sargs is NULL");
@@ -1448,11 +1405,9 @@ int spc_variability_nudge_f64(const spc_vnudge_args *a, void *stream)
     p.qt_std = (double *)a->qt_std; p.status = a->status;
     // Planes that fit the LDS (KT levels x nij x 16 B <= 150 KiB, KT a power of two <= 16; 64 x 64 planes: KT = 2)
     // are solved there (spc_vnudge2.hpp); larger planes (> ~9 000 points) keep the sweeping kernel.  SPC_VN_LDS=0: A/B.
-    int kt = 16, log2_kt = 4;
-    const int cn = p.nij < 8192 ? p.nij : 8192, nleaf_max = p.nij > 8192 ? VN_MAXLEAF : vn_count_leaves(cn);
-    auto lds_need = [&](int t) { return (size_t)t * vn2_plane(p.nij) * 16 + (size_t)t * nleaf_max * 8 + VN2_THREADS * 12; };
-    while (kt > 1 && lds_need(kt) > (size_t)VN2_MAX_LDS) { kt >>= 1; --log2_kt; }
-    if (lds_need(kt) <= (size_t)VN2_MAX_LDS && env_int("SPC_VN_LDS", 1)) {
+    int kt, log2_kt, nleaf_max;
+    if (vn_lds_fit(p.nij, &kt, &log2_kt, &nleaf_max)) {
+        auto lds_need = [&](int t) { return vn_lds_need(p.nij, nleaf_max, t); };
         // many workgroups (more than two rounds of one per CU): half the levels and half the threads per workgroup where
         // that lets TWO workgroups share a CU's LDS -- one's barriers and serial steps overlap the other's sums
         int nthreads = VN2_THREADS;
@@ -1510,66 +1465,36 @@ int spc_device_count(void)
     return n;
 }
 
+int spc_describe_launch(const spc_dims *d, int pass, int flags, int elem_size, char *buf, int buflen)
+{
+    int rc = validate(d);
+    if (rc) return rc;
+    if (!buf || buflen < 1) return fail(SPC_ERR_INVALID_ARGUMENT, "%sdescribe_launch: no buffer");
+    if (elem_size != 8 && elem_size != 4) return fail(SPC_ERR_INVALID_ARGUMENT, "%sdescribe_launch: elem_size must be 8 or 4");
+    Choice c = {};
+    rc = elem_size == 8 ? describe_impl<double>(d, pass, flags, &c) : describe_impl<float>(d, pass, flags, &c);
+    if (rc) return rc;
+    const char *ty = elem_size == 8 ? "f64" : "f32";
+    char name[160];
+    if (pass == 0)
+        snprintf(name, sizeof(name), "k_forward<%s,%s,%d,%d,wt=%d,blk=%d,pre=%d>", ty, c.full ? "full" : "lean", GEO_NG[c.geo], GEO_NL[c.geo],
+                 c.wt, c.blk, c.pre);
+    else if (pass == 1)
+        snprintf(name, sizeof(name), "k_backward<%s,%d,%d,wt=%d,blk=%d,pre=%d>", ty, GEO_NG[c.geo], GEO_NL[c.geo], c.wt, c.blk, c.pre);
+    else if (pass == 4)
+        snprintf(name, sizeof(name), "k_backward_cons2<%s,%d,%d>", ty, GEO_NG[c.geo], GEO_NL[c.geo]);
+    else
+        snprintf(name, sizeof(name), "%s<%s>", c.kernel, ty);
+    return snprintf(buf, (size_t)buflen, "%s cb=%d grid=%u block=%d lds=%lld", name, c.cb, c.grid, c.blk, (long long)c.smem);
+}
+
 int spc_pick_cols_per_block(const spc_dims *d, int pass)
 {
     int rc = validate(d);
     if (rc) return rc;
-    switch (pass) {
-    case 0: return pick_cb(d, 0, true, sizeof(double), k_forward<double, false, 0, 0, 0>);
-    case 1: return pick_cb(d, 1, false, sizeof(double), k_backward<double, 0, 0, 0>);
-    case 2: return pick_cb(d, 2, true, sizeof(double), k_cloud_idx<double>);
-    case 3: return pick_cb(d, 3, false, sizeof(double), k_diag<double>);
-    case 4: return pick_cb(d, 4, false, sizeof(double), k_backward_cons2<double, 0, 0>);
-    default: return fail(SPC_ERR_INVALID_ARGUMENT, "%spass must be 0..4");
-    }
-}
-
-static unsigned copy_grid(void)
-{
-    static const unsigned g = [] { const char *e = getenv("SPC_COPY_GRID"); return e ? (unsigned)atoi(e) : 2048u; }();
-    return g ? g : 2048u;
-}
-
-int spc_stream_copy(void *dst, const void *src, int64_t bytes, void *stream)
-{
-    if (bytes < 0 || (bytes & 15) || !dst || !src) return fail(SPC_ERR_INVALID_ARGUMENT, "%sstream_copy: bytes must be a multiple of 16, pointers non-NULL");
-    if (bytes == 0) return SPC_OK;
-    hipLaunchKernelGGL(k_copy16, dim3(copy_grid()), dim3(BLOCK), 0, (hipStream_t)stream, (uint4 *)dst, (const uint4 *)src, bytes / 16);
-    return launch_status("k_copy16");
-}
-
-int spc_stream_probe(int n_read, int n_write, void *dst, const void *src, int64_t bytes_per_stream, int grid, void *stream)
-{
-    if (bytes_per_stream <= 0 || (bytes_per_stream & 15) || !dst || !src || grid <= 0)
-        return fail(SPC_ERR_INVALID_ARGUMENT, "%sstream_probe: bad arguments");
-    const int64_t n16 = bytes_per_stream / 16;
-    unsigned *sink = (unsigned *)dst;
-#define PROBE(NR_, NW_) \
-    if (n_read == NR_ && n_write == NW_) { \
-        hipLaunchKernelGGL((k_probe<NR_, NW_>), dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (uint4 *)dst, (const uint4 *)src, n16, n16, sink); \
-        return launch_status("k_probe"); \
-    }
-    PROBE(1, 1) PROBE(1, 0) PROBE(0, 1) PROBE(2, 1) PROBE(14, 7) PROBE(16, 7) PROBE(8, 0) PROBE(0, 7) PROBE(4, 2)
-#undef PROBE
-    // n_read = 114 / 214: the 14 R + 7 W mix with 512- / 1024-thread workgroups, i.e. 8 KiB / 16 KiB contiguous per
-    // stream per workgroup iteration instead of 4 KiB (does the mix ceiling move with the burst length?)
-    if (n_read == 114 && n_write == 7) {
-        hipLaunchKernelGGL((k_probe<14, 7, 512>), dim3(grid), dim3(512), 0, (hipStream_t)stream, (uint4 *)dst, (const uint4 *)src, n16, n16, sink);
-        return launch_status("k_probe");
-    }
-    if (n_read == 214 && n_write == 7) {
-        hipLaunchKernelGGL((k_probe<14, 7, 1024>), dim3(grid), dim3(1024), 0, (hipStream_t)stream, (uint4 *)dst, (const uint4 *)src, n16, n16, sink);
-        return launch_status("k_probe");
-    }
-    return fail(SPC_ERR_UNSUPPORTED, "%sstream_probe: stream mix not instantiated");
-}
-
-int spc_stream_copy_f64(void *dst, const void *src, int64_t bytes, void *stream)
-{
-    if (bytes < 0 || (bytes & 7) || !dst || !src) return fail(SPC_ERR_INVALID_ARGUMENT, "%sstream_copy_f64: bytes must be a multiple of 8, pointers non-NULL");
-    if (bytes == 0) return SPC_OK;
-    hipLaunchKernelGGL(k_copy8, dim3(2048), dim3(BLOCK), 0, (hipStream_t)stream, (double *)dst, (const double *)src, bytes / 8);
-    return launch_status("k_copy8");
+    Choice c = {};
+    rc = describe_impl<double>(d, pass, 1, &c);     // forward: lean, with the fused index map
+    return rc ? rc : c.cb;
 }
 
 }  // extern "C"

@@ -34,7 +34,7 @@ def test_header_symbols_all_exported_and_bound(lib):
 
 
 def test_abi_version_and_error_text(lib):
-    assert lib.spc_abi_version() == _abi.ABI_VERSION == 2
+    assert lib.spc_abi_version() == _abi.ABI_VERSION == 3
     assert isinstance(lib.spc_last_error(), bytes)
 
 
@@ -84,10 +84,43 @@ def test_invalid_arguments_are_rejected_without_a_gpu(lib):
 def test_cols_per_block_heuristic(lib):
     small = _abi.Dims(1024, 91, 160, 91, 92, 160, 1, 0)
     big = _abi.Dims(348528, 91, 160, 91, 92, 160, 1, 0)
-    assert lib.spc_pick_cols_per_block(ctypes.byref(small), 0) == 1
+    assert lib.spc_pick_cols_per_block(ctypes.byref(small), 0) == 4      # 4 columns per 1024-thread workgroup
     assert lib.spc_pick_cols_per_block(ctypes.byref(big), 0) == 8
     tall = _abi.Dims(348528, 137, 512, 137, 138, 512, 1, 0)   # backward LDS: 6*512+137 doubles per column
     assert 1 <= lib.spc_pick_cols_per_block(ctypes.byref(tall), 1) <= 2
+
+
+def test_describe_launch_names_the_instantiation_the_launcher_would_pick(lib):
+    """spc_describe_launch is pure host logic (the occupancy query falls back without a device): the documented
+    size classes of the K1 / K3 dispatch read back as instantiation names."""
+    def d(n, nG=91, nL=160, pad=0, cb=0):
+        return _abi.Dims(n, nG, nL, nG + pad, nG + 1 + pad, nL + pad, 1, cb)
+    k1 = lambda n, **kw: _abi.describe_launch(lib, d(n, **kw), 0, 1).split()[0]       # noqa: E731
+    k3 = lambda n, **kw: _abi.describe_launch(lib, d(n, **kw), 1, 0).split()[0]       # noqa: E731
+    assert k1(200) == "k_forward<f64,lean,91,160,wt=1,blk=256,pre=1>"
+    assert k1(300) == "k_forward<f64,lean,91,160,wt=1,blk=512,pre=1>"
+    assert k1(1024) == "k_forward<f64,lean,91,160,wt=1,blk=1024,pre=1>"
+    assert k1(1025) == "k_forward<f64,lean,91,160,wt=1,blk=256,pre=0>"
+    assert k1(35718) == "k_forward<f64,lean,91,160,wt=0,blk=256,pre=0>"
+    assert k1(35718, pad=3) == "k_forward<f64,lean,0,0,wt=0,blk=256,pre=0>"          # padded pitch: run-time geometry
+    assert k1(1024, nG=137, nL=512) == "k_forward<f64,lean,137,512,wt=1,blk=256,pre=1>"
+    assert k3(1024) == "k_backward<f64,91,160,wt=1,blk=1024,pre=1>"
+    assert k3(1025) == "k_backward<f64,91,160,wt=1,blk=256,pre=0>"
+    assert k3(25000) == "k_backward<f64,91,160,wt=0,blk=256,pre=0>"
+    assert k3(25001) == "k_backward<f64,91,160,wt=0,blk=256,pre=1>"
+    assert k3(4096, nG=19) == "k_backward<f64,19,160,wt=1,blk=256,pre=0>"
+    full = _abi.describe_launch(lib, d(4096), 0, 3)
+    assert full.startswith("k_forward<f64,full,91,160,wt=1,blk=256,pre=0> cb=")
+    assert _abi.describe_launch(lib, d(4096), 4, 0).startswith("k_backward_cons2<f64,91,160> cb=")
+    assert _abi.describe_launch(lib, d(4096), 0, 1, 4).startswith("k_forward<f32,lean,91,160,")
+    txt = _abi.describe_launch(lib, d(35718), 0, 1)
+    fields = dict(kv.split("=") for kv in txt.split()[1:])
+    assert int(fields["cb"]) * int(fields["grid"]) >= 35718 > int(fields["cb"]) * (int(fields["grid"]) - 1)
+    with pytest.raises(_abi.SpcInvalidArgument):
+        _abi.describe_launch(lib, d(10), 7, 0)
+    assert lib.spc_vnudge_workspace_bytes(2, 64, 64, 160) == 2 * 2 * 64 * 64 * 160 * 8
+    assert lib.spc_vnudge_workspace_bytes(2, 128, 128, 160) == 0          # planes too large for the LDS path
+    assert lib.spc_vnudge_workspace_bytes(2, 0, 64, 160) < 0
 
 
 def test_missing_library_fails_loudly(tmp_path):

@@ -73,8 +73,9 @@ def test_full_size_config(eng, cfg):
     assert numpy.abs(F["f_thl"][rows] - rf["f_thl"]).max() <= 8 * EPS * thl_scale / DT
     assert numpy.abs(F["f_thl"][rows] - rf["f_thl"]).max() <= 1e-10 * numpy.abs(rf["f_thl"]).max()   # north-star bar
 
-    # (1b) the LEAN hot-path plans (what bench.py times: at these sizes first-generation K1, 8-column second-generation
-    # K3 for config 4) against the full-output launches above, bit for bit on the WHOLE batch
+    # (1b) the LEAN hot-path plans (what bench.py times; at these sizes k_forward<..,wt=0,blk=256,pre=0> and
+    # k_backward<..,wt=0,blk=256,pre=1>, see tests/test_dispatch_gpu.py) against the full-output launches above, bit for
+    # bit on the WHOLE batch
     import ctypes
     fp, bp = eng.plan_exchange(g, zf_d, zh_d, p, 1.0, 1.0, DT)
     sptr = ctypes.c_void_p(torch.cuda.current_stream(eng.device).cuda_stream)

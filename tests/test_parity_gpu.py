@@ -394,124 +394,6 @@ def test_the_plans_bench_py_times_are_bit_checked(eng, cfg, pad):
         assert_bits(k, host(bp.outputs[k]), ref_b[k])
 
 
-V2_VARIANTS = {(91, 160): ["2,128", "2,192", "4,256", "4,320", "8,512"], (137, 512): ["2,512", "2,256"],
-               (19, 160): ["4,256", "4,320"]}
-
-
-@pytest.mark.parametrize("nG,nL", [(91, 160), (137, 512), (19, 160)])
-def test_second_generation_kernels_every_variant_ragged_tails_and_edges(eng, nG, nL):
-    """The compile-time-geometry kernels of csrc/spc_v2.hpp (what the lean hot-path plans launch on contiguous
-    fp64 batches): every instantiated (columns-per-workgroup, workgroup-size) variant, column counts that leave
-    ragged last slabs (odd counts: the last 16-B pair is half outside the array), shared and per-column LES
-    grids, Zf given or recomputed, with and without start_index -- bit-checked against the C oracle; then the
-    NaN / Inf / exact-hit / clamping columns of test_edge_columns through the same kernels."""
-    import ctypes
-    import os
-    sptr = ctypes.c_void_p(torch.cuda.current_stream(eng.device).cuda_stream)
-    saved = {k: os.environ.get(k) for k in ("SPC_V2_K1", "SPC_V2_K3", "SPC_V2_REMAP")}
-    try:
-        for vi, var in enumerate(V2_VARIANTS[(nG, nL)]):
-            os.environ["SPC_V2_K1"] = os.environ["SPC_V2_K3"] = var
-            os.environ["SPC_V2_REMAP"] = str(vi % 2)
-            for n, per_col in ((1, False), (2, False), (3, False), (5, True), (37, False), (1001, False), (260, True)):
-                gcm, zf, zh, prof = synthetic.make_batch(n, nG, nL, seed=8100 + n, per_column_grid=per_col, couple_surface=False)
-                g, p = to_dev(gcm, eng.device), to_dev(prof, eng.device)
-                zf_d, zh_d = torch.from_numpy(zf).to(eng.device), torch.from_numpy(zh).to(eng.device)
-                fp, bp = eng.plan_exchange(g, zf_d, zh_d, p, FACTOR, FACTOR, DT)
-                ref_f = oracle_c.forward(gcm, zf, zh, prof, FACTOR, DT, couple_surface=False)
-                ref_b = oracle_c.backward(gcm, None, zf, prof, FACTOR, DT)
-                bp2 = eng.plan_backward(g, zf_d, p, FACTOR, DT, Zf=torch.from_numpy(ref_f["Zf"]).to(eng.device))
-                for pl in (fp, bp, bp2):
-                    for t in pl.outputs.values():
-                        t.fill_(float("nan")) if t.is_floating_point() else t.fill_(-7)
-                    pl.launch_raw(sptr)
-                torch.cuda.synchronize()
-                tag = "variant %s n=%d per_col=%s: " % (var, n, per_col)
-                F = {k: host(v) for k, v in fp.outputs.items()}
-                assert_bits(tag + "idx", F["idx"], ref_f["idx"])
-                for k in ("f_u", "f_v", "f_qt", "f_ql", "ql_ref", "f_ps"):
-                    assert_bits(tag + k, F[k], ref_f[k])
-                assert_close_scaled(tag + "f_thl", F["f_thl"], ref_f["f_thl"], 8 * EPS, numpy.abs(ref_f["thl"]).max() * abs(FACTOR) / DT)
-                for k in ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A"):
-                    assert_bits(tag + k, host(bp.outputs[k]), ref_b[k])
-                    assert_bits(tag + k + " (Zf given)", host(bp2.outputs[k]), ref_b[k])
-                assert_bits(tag + "start_index", host(bp2.outputs["start_index"]), ref_b["start_index"])
-        if (nG, nL) == (91, 160):
-            gcm, zf, zh, prof = make_edge_batch()[:4]
-            with numpy.errstate(all="ignore"):
-                ref_f = orc.forward_batched(gcm, prof, zf, zh, FACTOR, DT, couple_surface=False)
-                ref_b = orc.backward_batched(gcm, ref_f["Zf"], prof, zf, FACTOR, DT)
-            g, p = to_dev(gcm, eng.device), to_dev(prof, eng.device)
-            zf_d, zh_d = torch.from_numpy(zf).to(eng.device), torch.from_numpy(zh).to(eng.device)
-            for var in V2_VARIANTS[(nG, nL)]:
-                os.environ["SPC_V2_K1"] = os.environ["SPC_V2_K3"] = var
-                fp, bp = eng.plan_exchange(g, zf_d, zh_d, p, FACTOR, FACTOR, DT)
-                fp.launch_raw(sptr)
-                bp.launch_raw(sptr)
-                torch.cuda.synchronize()
-                F = {k: host(v) for k, v in fp.outputs.items()}
-                assert_bits("edge idx", F["idx"], ref_f["idx"])
-                for k in ("f_u", "f_v", "f_qt", "f_ql", "ql_ref", "f_ps"):
-                    assert_bits("edge " + var + " " + k, F[k], ref_f[k])
-                ok = numpy.isfinite(ref_f["f_thl"])
-                assert numpy.array_equal(numpy.isfinite(F["f_thl"]), ok)
-                assert numpy.abs(F["f_thl"][ok] - ref_f["f_thl"][ok]).max() <= 8 * EPS * numpy.abs(ref_f["thl"][numpy.isfinite(ref_f["thl"])]).max() / DT
-                for k in ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A"):
-                    assert_bits("edge " + var + " " + k, host(bp.outputs[k]), ref_b[k])
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-
-
-def test_second_generation_kernels_random_batch_sizes(eng):
-    """Soak of the compile-time-geometry kernels: random column counts (ragged last slabs of every parity), random
-    variant, shared / per-column LES grid, forced on through SPC_V2_K1 / SPC_V2_K3 -- each launch bit-checked against
-    the plain-C oracle.  SPC_FUZZ_TRIALS / SPC_FUZZ_SEED scale it (default 24 trials)."""
-    import ctypes
-    import os
-    rng = numpy.random.default_rng(int(os.environ.get("SPC_FUZZ_SEED", "2026")) + 1)
-    sptr = ctypes.c_void_p(torch.cuda.current_stream(eng.device).cuda_stream)
-    saved = {k: os.environ.get(k) for k in ("SPC_V2_K1", "SPC_V2_K3", "SPC_V2_REMAP", "SPC_V2_NT")}
-    try:
-        for trial in range(max(6, int(os.environ.get("SPC_FUZZ_TRIALS", "24")))):
-            nG, nL = [(91, 160), (137, 512), (19, 160)][int(rng.integers(0, 3))]
-            n = int(rng.integers(1, 2200 if nL == 160 else 500))
-            per_col = bool(rng.integers(0, 2))
-            os.environ["SPC_V2_K1"] = str(rng.choice(V2_VARIANTS[(nG, nL)]))
-            os.environ["SPC_V2_K3"] = str(rng.choice(V2_VARIANTS[(nG, nL)]))
-            os.environ["SPC_V2_REMAP"] = str(int(rng.integers(0, 2)))
-            os.environ["SPC_V2_NT"] = str(int(rng.integers(0, 2)))
-            gcm, zf, zh, prof = synthetic.make_batch(n, nG, nL, seed=9100 + trial, per_column_grid=per_col, couple_surface=False)
-            g, p = to_dev(gcm, eng.device), to_dev(prof, eng.device)
-            zf_d, zh_d = torch.from_numpy(zf).to(eng.device), torch.from_numpy(zh).to(eng.device)
-            fp, bp = eng.plan_exchange(g, zf_d, zh_d, p, FACTOR, FACTOR, DT)
-            for pl in (fp, bp):
-                for t in pl.outputs.values():
-                    t.fill_(float("nan")) if t.is_floating_point() else t.fill_(-7)
-                pl.launch_raw(sptr)
-            torch.cuda.synchronize()
-            ref_f = oracle_c.forward(gcm, zf, zh, prof, FACTOR, DT, couple_surface=False)
-            ref_b = oracle_c.backward(gcm, None, zf, prof, FACTOR, DT)
-            tag = "trial %d %d<->%d n=%d per_col=%s K1=%s K3=%s: " % (trial, nG, nL, n, per_col, os.environ["SPC_V2_K1"],
-                                                                       os.environ["SPC_V2_K3"])
-            F = {k: host(v) for k, v in fp.outputs.items()}
-            assert_bits(tag + "idx", F["idx"], ref_f["idx"])
-            for k in ("f_u", "f_v", "f_qt", "f_ql", "ql_ref", "f_ps"):
-                assert_bits(tag + k, F[k], ref_f[k])
-            assert_close_scaled(tag + "f_thl", F["f_thl"], ref_f["f_thl"], 8 * EPS, numpy.abs(ref_f["thl"]).max() * abs(FACTOR) / DT)
-            for k in ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A"):
-                assert_bits(tag + k, host(bp.outputs[k]), ref_b[k])
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-
-
 def test_exner_power_accuracy_and_special_values(eng):
     """spc_pow, the specialised x**(-rd/cp) of iexner (sputils.py:33-34), through K5's THL = T * iexner(Pf) with T = 1:
     pressures from 1e-3 Pa to 2e5 Pa (the atmosphere needs 1 Pa .. 1.1e5 Pa), tiny / huge normal numbers, and the

@@ -183,7 +183,10 @@ def test_spifs_output_through_the_driver(tmp_path):
                 want = got[("les" if name[2].islower() or name == "wthl" else "gcm", les.grid_index, name)][s]
                 assert numpy.array_equal(c[name][s], numpy.asarray(want, dtype=numpy.float32)), (name, s)
             assert numpy.isfinite(c["Tv"][s]).all() and numpy.isfinite(c["t"][s]).all() and (c["Zf"][s][:-1] > c["Zf"][s][1:]).all()
-            assert numpy.array_equal(c["ql_water"][s], (c["ql"][s].astype(numpy.float64) - c["ql_ice"][s]).astype(numpy.float32)) or True
+            # ql_water is float32(ql - ql_ice) of the float64 slab means (spcpl.py:402); the file holds float32(ql) and
+            # float32(ql_ice), so recomputing it from them may differ by the rounding of the two inputs
+            diff = numpy.abs(c["ql_water"][s].astype(numpy.float64) - (c["ql"][s].astype(numpy.float64) - c["ql_ice"][s]))
+            assert diff.max() <= 2 * numpy.finfo(numpy.float32).eps * max(float(numpy.abs(c["ql"][s]).max()), 1e-30)
 
 
 def test_surface_fluxes_dict_form_and_set_les_state():

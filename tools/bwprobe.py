@@ -4,8 +4,8 @@ kernels (K1: 14 read + 7 write streams, K3: 16 + 7), for several grid sizes.  GB
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from sp_coupler_amd.engine import Engine
-eng = Engine("cuda:0")
+from tools import spc_tools
+tl = spc_tools.load()
 s = torch.cuda.current_stream(); sp = ctypes.c_void_p(s.cuda_stream)
 src = torch.empty(3 << 30, dtype=torch.uint8, device="cuda").random_(0, 255)
 dst = torch.empty(2 << 30, dtype=torch.uint8, device="cuda")
@@ -38,8 +38,8 @@ if MODES == "small":
             def run(k, nr=nr, nw=nw, pp=pp, grid=grid, slots=slots):
                 for i in range(k):
                     o = i % slots
-                    rc = eng.lib.spc_stream_probe(nr, nw, dst.data_ptr() + o * nw * pp, src.data_ptr() + o * nr * pp, pp, grid, sp)
-                    assert rc == 0, eng.lib.spc_last_error()
+                    rc = tl.spc_stream_probe(nr, nw, dst.data_ptr() + o * nw * pp, src.data_ptr() + o * nr * pp, pp, grid, sp)
+                    assert rc == 0, tl.spc_tools_last_error()
             heat(run, 50)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(s); run(2000); b.record(s); torch.cuda.synchronize()
@@ -52,8 +52,8 @@ for nr, nw, per in cases or ((1, 1, 1 << 30), (1, 0, 1 << 30), (8, 0, 128 << 20)
     for grid in ((2048,) if MODES == "stride" else (256, 512, 1024, 2048, 4096) if cases else (1024, 2048, 4096, 16384)):
         def run(k):
             for _ in range(k):
-                rc = eng.lib.spc_stream_probe(nr, nw, dst.data_ptr(), src.data_ptr(), per, grid, sp)
-                assert rc == 0, eng.lib.spc_last_error()
+                rc = tl.spc_stream_probe(nr, nw, dst.data_ptr(), src.data_ptr(), per, grid, sp)
+                assert rc == 0, tl.spc_tools_last_error()
         heat(run, 5)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(s); run(40); b.record(s); torch.cuda.synchronize()

@@ -12,6 +12,7 @@ import torch  # noqa: E402
 
 from sp_coupler_amd import synthetic  # noqa: E402
 from sp_coupler_amd.engine import Engine  # noqa: E402
+from tools import spc_tools  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 rot = int(sys.argv[2]) if len(sys.argv) > 2 else 8
@@ -30,8 +31,8 @@ src = torch.empty(1 << 28, dtype=torch.uint8, device="cuda").random_(0, 255)    
 dst = torch.empty_like(src)
 torch.cuda.synchronize()
 for it in range(3):
-    eng.stream_copy(dst, src)
-    eng.lib.spc_stream_copy_f64(dst.data_ptr(), src.data_ptr(), src.numel(), sptr)
+    spc_tools.stream_copy(dst, src)
+    spc_tools.stream_copy(dst, src, f64=True)
 for i in range(3 * rot):
     fpl[i % rot].launch_raw(sptr)
     bpl[i % rot].launch_raw(sptr)

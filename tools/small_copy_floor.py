@@ -4,8 +4,8 @@ a pure streaming copy of 11.3 MB (22.6 MB read+write) per launch, rotating throu
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from sp_coupler_amd.engine import Engine
-eng = Engine("cuda:0")
+from tools import spc_tools
+tl = spc_tools.load()
 nb = 11_300_000 // 16 * 16
 big = torch.empty(1 << 30, dtype=torch.uint8, device="cuda").random_(0, 255)
 out = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
@@ -14,7 +14,7 @@ slots = (1 << 30) // nb
 def run(iters):
     for i in range(iters):
         o = (i % slots) * nb
-        eng.lib.spc_stream_copy(out.data_ptr() + o, big.data_ptr() + o, nb, sp)
+        tl.spc_stream_copy(out.data_ptr() + o, big.data_ptr() + o, nb, sp)
 run(50); torch.cuda.synchronize()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record(s); run(400); b.record(s); torch.cuda.synchronize()

@@ -218,17 +218,18 @@ class Workload:
     """ROTATE batches of one configuration resident in HBM + the exchange plans bench.py times."""
 
     def __init__(self, eng, n_cols, nG, nL, seed, rotate, factor, dt, cols_per_block=0, keep_host=False):
-        import torch
         from sp_coupler_amd import synthetic
         self.n_cols, self.nG, self.nL, self.rotate = n_cols, nG, nL, rotate
         self.fplans, self.bplans, self.host0 = [], [], None
+        need = ("U", "V", "T", "SH", "QL", "QI", "Pfull", "Phalf", "A", "Zgfull", "Zghalf",      # what the two plans read
+                "THL", "QT", "QL_ice", "PS")
         for r in range(rotate):
-            gcm, zf, zh, prof = synthetic.make_batch_tiled(n_cols, nG, nL, seed=seed + r, couple_surface=False)
+            # columns beyond the first 8192 are tiles of those with a per-tile perturbation, made ON THE DEVICE (same bits
+            # as synthetic.make_batch_tiled on the host; tile 0 is the host batch `verified` checks)
+            g, zf_d, zh_d, p, host = synthetic.make_batch_tiled_device(eng.device, n_cols, nG, nL, seed=seed + r,
+                                                                        couple_surface=False, keys=need)
             if r == 0 and keep_host:
-                self.host0 = (gcm, zf, zh, prof)
-            g = {k: torch.from_numpy(v).to(eng.device) for k, v in gcm.items()}
-            p = {k: torch.from_numpy(v).to(eng.device) for k, v in prof.items()}
-            zf_d, zh_d = torch.from_numpy(zf).to(eng.device), torch.from_numpy(zh).to(eng.device)
+                self.host0 = host
             fp, bp = eng.plan_exchange(g, zf_d, zh_d, p, factor, factor, dt, cols_per_block=cols_per_block)
             self.fplans.append(fp)
             self.bplans.append(bp)
@@ -270,6 +271,46 @@ class Workload:
         return res["k1"], res["k3"]
 
 
+def self_launch(n_gpus, argv):
+    """Run `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a child process (this parent
+    has not imported torch, so nothing here has initialised a GPU) and return its exit code; the children's stdout --
+    rank 0's ONE JSON line -- and stderr pass straight through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rehearse_cpu(args, rank, world):
+    """The N > 1 launch path without a GPU (CPU tests of the self-launch): gloo rendezvous, this rank's shard of the
+    workload, barrier, max-over-ranks of a per-rank time -- rank 0 prints the JSON line with `value: null`."""
+    import torch
+    import torch.distributed as dist
+    from sp_coupler_amd import sharding, synthetic
+    dist.init_process_group("gloo")
+    cfg = args.config if args.config is not None else 4
+    total_cols = args.cols or synthetic.CONFIGS[cfg][0]
+    lo, hi = sharding.shard_range(total_cols, rank, world)
+    dist.barrier()
+    tt = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    rows = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(rows, torch.tensor([lo, hi]))
+    if rank == 0:
+        print(json.dumps({"metric": "SP column-exchanges/sec (GCM<->LES forcing+tendency)", "value": None, "rehearsal": "cpu",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "backend": "gloo",
+                          "max_over_ranks_s": float(tt.item()), "shards": [[int(a), int(b)] for a, b in rows],
+                          "config": {"workload": "config %d, %d columns over %d ranks" % (cfg, total_cols, world)}}))
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -286,19 +327,32 @@ def main():
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in API (Coupler.step) rate at N=1")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N>1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--device", type=int, default=None, help="force this HIP device for every rank (rehearsal on a 1-GPU box)")
+    ap.add_argument("--no-anchor", action="store_true", help="skip the config-4-on-one-GPU `scaling_anchor` extra at N=1")
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="N>1 launch mechanics only (rendezvous, sharding, barrier, max-reduction over gloo; no GPU work): CPU tests")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` launched plainly (no torchrun around it): start the N ranks as FRESH CHILD PROCESSES
+    # before this process has imported torch or touched the GPU, let rank 0's JSON line through, return their exit code.
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (torch.distributed.run must start one rank per GPU)" % (args.gpus, world))
+    if args.rehearse_cpu:
+        return rehearse_cpu(args, rank, world)
 
     import numpy
     import torch
     from sp_coupler_amd import sharding, synthetic
     from sp_coupler_amd.engine import Engine
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    if world > 1 and args.device is None and torch.cuda.device_count() < world:
+        sys.exit("bench.py --gpus %d needs %d visible GPUs, found %d (--device D puts every rank on GPU D: a rehearsal of the "
+                 "launch path, not a measurement)" % (world, world, torch.cuda.device_count()))
     if args.device is not None:
         local = args.device
     torch.cuda.set_device(local)
@@ -422,6 +476,34 @@ def main():
                  "k3_algorithmic_bytes_per_launch": a2["k3_launch"] * n2}
         del w2
 
+    anchor = None
+    if world == 1 and cfg == 3 and not args.cols and not args.no_anchor and not args.no_kernel_events:
+        # the N = 1 point of the series the N > 1 runs measure (config 4, 348 528 columns, strong scaling): the whole of
+        # config 4 on this ONE GPU (14 GB live; one batch -- 55x the Infinity Cache -- so no rotation is needed)
+        n4, nG4, nL4, seed4 = synthetic.CONFIGS[4]
+        w4 = Workload(eng, n4, nG4, nL4, seed4, 1, factor, dt_gcm, args.cols_per_block)
+        k4steps = max(20, min(args.steps, 100))
+        w4.heat(sptr)
+        for i in range(max(args.warmup, 3)):
+            w4.step(i, sptr)
+        torch.cuda.synchronize()
+        t4 = time.perf_counter()
+        for i in range(k4steps):
+            w4.step(i, sptr)
+        torch.cuda.synchronize()
+        el4 = time.perf_counter() - t4
+        a4 = algorithmic_bytes(nG4, nL4)
+        s1, s3 = w4.kernel_times(stream, sptr, launches=60)
+        anchor = {"workload": "config 4: 348528 synthetic SP columns on ONE GPU (the series `--gpus N` shards over N GPUs), "
+                              "91 GCM <-> 160 LES levels, fp64, shared LES grid, 1 batch of 14 GB resident in HBM",
+                  "value": n4 * k4steps / el4, "unit": "column-exchanges/s", "n_gpus": 1, "steps": k4steps,
+                  "ms_per_step": el4 / k4steps * 1e3, "k1_avg_launch_us": s1, "k3_avg_launch_us": s3,
+                  "k1_frac": a4["k1_launch"] * n4 / (s1 * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                  "k3_frac": a4["k3_launch"] * n4 / (s3 * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                  "note": "strong-scaling efficiency at N GPUs = value(N) / (N x this value)"}
+        del w4
+        torch.cuda.empty_cache()
+
     dropin = None
     if world == 1 and not args.no_dropin:
         try:
@@ -450,9 +532,10 @@ def main():
         "config": {"workload": wtxt, "total_cols": total_cols, "n_cols_per_gpu": n_cols, "nG": nG, "nL": nL,
                    "rotate": rotate, "launches_per_step": 2, "parallelism": "columns sharded, no collective"},
         "backend": (args.backend if world > 1 else None),
-        "series_note": ("N = 1 runs config 3 (35 718 columns, the largest config BASELINE.json places on ONE GPU); N > 1 shard config 4 "
-                        "(348 528 columns) -- per-GPU launches of 174 264 / 87 132 / 43 566 columns, which run at a higher fraction of the "
-                        "roofline than config 3's (DESIGN.md section 4); config 4 on one GPU: --config 4"),
+        "series_note": ("ONE workload per scaling series: `--gpus N` (N > 1) shards config 4 (348 528 columns) over N GPUs -- strong "
+                        "scaling; its N = 1 point is `scaling_anchor` of the N = 1 line (config 4 on one GPU).  The N = 1 headline "
+                        "`value` is config 3 (35 718 columns, the largest config BASELINE.json places on ONE GPU): do not divide "
+                        "value(N) by value(1)"),
         "bytes_per_exchange": ab["exchange"],
         "hbm_frac_whole_step": value / world * ab["exchange"] / 1e9 / HBM_PEAK_GBS,
     }
@@ -485,6 +568,8 @@ def main():
         out["cold_clock"] = cold
     if small is not None:
         out["small_batch"] = small
+    if anchor is not None:
+        out["scaling_anchor"] = anchor
     if dropin is not None:
         out["dropin"] = dropin
         out["dropin_value"] = dropin.get("batched_protocol", {}).get("value")

@@ -168,6 +168,29 @@ def make_batch_tiled(n_cols, nG=91, nL=160, seed=20261006, base=8192, couple_sur
     return g, zf, zh, p
 
 
+def make_batch_tiled_device(device, n_cols, nG=91, nL=160, seed=20261006, base=8192, couple_surface=True, keys=None):
+    """make_batch_tiled with the tiling done ON THE DEVICE: only the ``base`` columns are generated and cross PCIe, the
+    tiles and their perturbations are torch ops in HBM (IEEE add / multiply: the same bits as the host version, and
+    tile 0 IS the base batch).  Returns (gcm, zf, zh, prof) of device tensors plus the host base batch."""
+    import torch
+    host = make_batch(min(n_cols, base), nG, nL, seed, couple_surface)
+    gcm, zf, zh, prof = host
+    up = lambda d: {k: torch.from_numpy(v).to(device) for k, v in d.items() if keys is None or k in keys}   # noqa: E731
+    g, p = up(gcm), up(prof)
+    zf_d, zh_d = torch.from_numpy(zf).to(device), torch.from_numpy(zh).to(device)
+    if n_cols > base:
+        reps = -(-n_cols // base)
+        tile = torch.arange(reps, dtype=torch.float64, device=device).repeat_interleave(base)[:n_cols]
+        rep = lambda t: t.repeat(*((reps,) + (1,) * (t.dim() - 1)))[:n_cols].contiguous()                   # noqa: E731
+        g, p = {k: rep(v) for k, v in g.items()}, {k: rep(v) for k, v in p.items()}
+        g["T"] += 0.01 * tile[:, None]
+        g["U"] *= (1.0 + 1e-3 * tile[:, None])
+        p["THL"] += 0.02 * tile[:, None]
+        p["V"] -= 0.05 * tile[:, None]
+        p["PS"] += tile
+    return g, zf_d, zh_d, p, host
+
+
 def make_config(cfg_id, n_cols=None):
     n, nG, nL, seed = CONFIGS[cfg_id]
     return make_batch(n if n_cols is None else n_cols, nG, nL, seed)

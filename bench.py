@@ -171,13 +171,15 @@ def verify(fplan, bplan, ref_f, ref_b, n_ref, factor, dt):
                        "f_thl_max_rel_err": rel, "f_thl_elementwise": ew, "failures": bad}
 
 
-def dropin_rate(eng, n_les=1024, steps=30, warmup=3, per_les_steps=3):
+def dropin_rate(eng, n_les=1024, steps=30, warmup=5, per_les_steps=5):
     """Column-exchanges/s THROUGH THE DROP-IN API: driver.Coupler.step (gather -> set_les_forcings -> LES -> profiles
     -> set_gcm_tendencies) on the in-process synthetic GCM/LES pair, host buffers in, host buffers out every step
     (PCIe both ways), with the time spent inside the model objects' own methods subtracted.  Two transports:
-    the optional batched model protocol (one call per variable for all columns) and the reference's per-LES calls."""
+    the optional batched model protocol (one call per variable for all columns) and the reference's per-LES calls.
+    `breakdown`: a second pass of the batched protocol with every copy and launch bracketed by HIP events
+    (transfer.StepTrace): bytes and GB/s per PCIe copy, kernel time, and what is left for the host."""
     import torch
-    from sp_coupler_amd import models, spcpl
+    from sp_coupler_amd import models, spcpl, transfer
     from sp_coupler_amd.driver import Coupler
     spcpl.set_engine(eng)
     out = {"n_cols": n_les, "levels": "91<->160", "unit": "column-exchanges/s",
@@ -196,12 +198,36 @@ def dropin_rate(eng, n_les=1024, steps=30, warmup=3, per_les_steps=3):
     out["batched_protocol"] = {"value": n_les * steps / (wall - models.model_seconds), "steps": steps,
                                "ms_per_step_coupler": (wall - models.model_seconds) / steps * 1e3,
                                "ms_per_step_models": models.model_seconds / steps * 1e3}
-    # the reference's transport: ~20 getter / setter calls per column per step (spcpl.py:341-347, 535-542, 748-766)
+    # the same steps again with HIP events around every copy / launch (the events cost a little host time themselves)
+    transfer.trace = tr = transfer.StepTrace()
+    models.model_seconds = 0.0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        cpl.step()
+    torch.cuda.synchronize()
+    wall_t = time.perf_counter() - t0
+    transfer.trace = None
+    summ = tr.summary()
+    per = {k: {"ms_per_step": v["ms"] / steps, "bytes_per_step": v["bytes"] // steps, "GBs": v["GBs"]} for k, v in summ.items()}
+    dev_ms = sum(v["ms"] for v in summ.values()) / steps
+    coupler_ms = (wall_t - models.model_seconds) / steps * 1e3
+    h2d = [v for k, v in summ.items() if k.startswith("h2d")]
+    d2h = [v for k, v in summ.items() if k.startswith("d2h")]
+    out["breakdown"] = {"per_step": per, "ms_per_step_coupler_traced": coupler_ms, "ms_per_step_on_device_or_wire": dev_ms,
+                        "ms_per_step_host_outside_copies_and_kernels": coupler_ms - dev_ms,
+                        "h2d_GBs": sum(v["bytes"] for v in h2d) / max(sum(v["ms"] for v in h2d), 1e-9) / 1e6,
+                        "d2h_GBs": sum(v["bytes"] for v in d2h) / max(sum(v["ms"] for v in d2h), 1e-9) / 1e6,
+                        "pcie_bytes_per_step": sum(v["bytes"] for v in h2d + d2h) // steps,
+                        "pcie_ms_per_step": sum(v["ms"] for v in h2d + d2h) / steps}
+    # the reference's transport: ~35 getter / setter calls per column per step (spcpl.py:341-347, 535-542, 748-766)
+    # through the UNCHANGED loop shape of splib.step (splib.py:317-332) -- per-LES spcpl calls on a list of LES objects
     gcm2, ens2 = models.make_batched_models(n_les, nG=91, nL=160, seed=3)
-    gcm2.__class__ = models.SyntheticGCM
+    gcm2.__class__ = models.TimedSyntheticGCM
     cpl2 = Coupler(gcm2, [ens2[i] for i in range(n_les)])
     cpl2.step()
+    cpl2.step()
     torch.cuda.synchronize()
+    models.model_seconds = 0.0
     t0 = time.perf_counter()
     for _ in range(per_les_steps):
         cpl2.step()
@@ -209,7 +235,10 @@ def dropin_rate(eng, n_les=1024, steps=30, warmup=3, per_les_steps=3):
     wall2 = time.perf_counter() - t0
     out["per_les_protocol"] = {"value": n_les * per_les_steps / wall2, "steps": per_les_steps,
                                "ms_per_step": wall2 / per_les_steps * 1e3,
-                               "note": "model time NOT subtracted (the per-column Python calls ARE the cost)"}
+                               "value_model_time_subtracted": n_les * per_les_steps / (wall2 - models.model_seconds),
+                               "ms_per_step_models": models.model_seconds / per_les_steps * 1e3,
+                               "note": "`value`: wall time, model time NOT subtracted; `value_model_time_subtracted`: minus the "
+                                       "time inside the stand-in models' own getters / setters (35 calls per column and step)"}
     spcpl.set_engine(None)
     return out
 

@@ -47,18 +47,19 @@ class Coupler:
             return [wall], spcpl.get_les_profiles_batched(self.les_models, True, diagnostics=diag)
         pool = RequestsPool()
         reqs, profile_reqs = [], {}
+        pending = pool.requests
         for les in self.les_models:
             req = les.evolve_model(model_time + offset, exactEnd=True)
             reqs.append(req)
-            pool.add_request(req)
+            pending.append(req)
             prof = spcpl.get_les_profiles(les, True)
             profile_reqs[les] = prof
-            for r in prof.values():
-                pool.add_request(r)
+            pending.extend(prof.values())
         pool.waitall()
-        les_profiles = {les: {k: r.result() for k, r in prof.items()} for les, prof in profile_reqs.items()}
+        # the request dicts go on as they are: spcpl resolves them column-block-wise when it packs the next launch
+        # (the reference resolves them here, one .result() per variable and column, splib.py:586-590)
         walls = [r.result() if hasattr(r, "result") else 0.0 for r in reqs]
-        return walls, les_profiles
+        return walls, profile_reqs
 
     # splib/splib.py:267-352
     def step(self):
@@ -91,8 +92,7 @@ class Coupler:
                                                   dt_gcm=delta_t, factor=self.les_forcing_factor,
                                                   couple_surface=self.cplsurf, qt_forcing=self.qt_forcing,
                                                   write=self.write):
-            for r in req.values():
-                pool.add_request(r)
+            pool.requests.extend(req.values())
         pool.waitall()
         wf += time.time()
 
@@ -122,8 +122,7 @@ class Coupler:
                                                   dt_gcm=spinup_length, factor=les_spinup_forcing_factor,
                                                   couple_surface=self.cplsurf, qt_forcing=self.qt_forcing,
                                                   write=self.write):
-            for r in req.values():
-                pool.add_request(r)
+            pool.requests.extend(req.values())
         pool.waitall()
         _, self.profiles = self.step_les_models(t_les + spinup_length, offset=0)
         if self.write and spcpl.writer is not None:                           # splib/splib.py:388-391

@@ -70,15 +70,22 @@ class _Checker:
 
 
 class _Plan:
-    def __init__(self, engine, fn, dims, args, keep, outputs):
-        self.engine, self._fn, self.dims, self.args, self._keep, self.outputs = engine, fn, dims, args, keep, outputs
-        self._dref, self._aref = ctypes.byref(dims), ctypes.byref(args)
+    """A validated, frozen launch: shapes checked once, ctypes argument block built once, tensors kept alive; ``launch``
+    is then ONE foreign call.  ``fn(*call_args, stream)`` is the C-ABI entry point."""
+
+    def __init__(self, engine, fn, call_args, keep, outputs, dims=None, args=None):
+        self.engine, self._fn, self._call, self._keep, self.outputs = engine, fn, tuple(call_args), keep, outputs
+        self.dims, self.args = dims, args
+
+    def set_scalars(self, factor, dt):
+        """forcing factor and time step of the next launches (they change between spin-up and coupled steps)"""
+        self.args.factor, self.args.dt = float(factor), float(dt)
 
     def launch(self, stream=None):
         """Enqueue the kernel on ``stream`` (default: torch's current stream). Returns outputs dict."""
         eng = self.engine
         with torch.cuda.device(eng.device):          # occupancy queries + launch on the engine's device
-            rc = self._fn(self._dref, self._aref, _stream_ptr(stream, eng.device))
+            rc = self._fn(*self._call, _stream_ptr(stream, eng.device))
         if rc:
             _abi.check(eng.lib, rc)
         return self.outputs
@@ -86,17 +93,50 @@ class _Plan:
     def launch_raw(self, stream_ptr):
         """Same with a pre-fetched ``ctypes.c_void_p`` stream handle (hot loops). The caller guarantees that the
         handle belongs to the engine's device and that this device is current (``torch.cuda.set_device``)."""
-        rc = self._fn(self._dref, self._aref, stream_ptr)
+        rc = self._fn(*self._call, stream_ptr)
         if rc:
             _abi.check(self.engine.lib, rc)
 
+    def describe(self):
+        """which kernel instantiation / slab size / grid the library picks for this plan (spc_describe_launch)"""
+        return _abi.describe_launch(self.engine.lib, self.dims, self._pass, self._flags(), 8 if self.engine.dtype == torch.float64 else 4)
+
 
 class ForwardPlan(_Plan):
-    pass
+    _pass = 0
+
+    def _flags(self):
+        a = self.args
+        full = any(getattr(a, f) for f in ("u", "v", "thl", "qt", "ps", "Zf", "Zh", "rainrate", "wthl"))
+        return (1 if a.idx else 0) | (2 if full else 0)
 
 
 class BackwardPlan(_Plan):
-    pass
+    @property
+    def _pass(self):
+        return 4 if self.args.conservative else 1
+
+    def _flags(self):
+        return 0
+
+
+class DiagnosticsPlan(_Plan):
+    _pass = 3
+
+    def _flags(self):
+        return 0
+
+
+class CloudIndexPlan(_Plan):
+    _pass = 2
+
+    def _flags(self):
+        return 0
+
+
+class SurfacePlan(_Plan):
+    def describe(self):
+        return "k_surface"
 
 
 class Engine:
@@ -213,14 +253,14 @@ class Engine:
                 setattr(a, name, ovec(name))
         a.factor, a.dt = float(factor), float(dt)
         dims = _abi.Dims(n, nG, nL, pitchG or nG, pitchGh or nG + 1, pitchL or nL, shared, int(cols_per_block))
-        return ForwardPlan(self, self._fwd, dims, a, ck.keep, res)
+        return ForwardPlan(self, self._fwd, (ctypes.byref(dims), ctypes.byref(a)), ck.keep, res, dims, a)
 
     def forward(self, *args, stream=None, **kw):
         return self.plan_forward(*args, **kw).launch(stream)
 
     # -- K2 standalone ----------------------------------------------------------------------
-    def cloud_indices(self, zh, Zh, stream=None, cols_per_block=0):
-        """searchsorted(zh, Zh, 'right')[:-1][::-1] per column (splib/spcpl.py:26, 764)."""
+    def plan_cloud_indices(self, zh, Zh, out=None, cols_per_block=0):
+        """searchsorted(zh, Zh, 'right')[:-1][::-1] per column (splib/spcpl.py:26, 764); ``out``: int32 [n x nG]."""
         n, nGp1 = int(Zh.shape[0]), int(Zh.shape[1])
         nG = nGp1 - 1
         nL = int(zh.shape[-1])
@@ -228,12 +268,17 @@ class Engine:
         Zh_ptr, pitchGh = ck.mat("Zh", Zh, n, nG + 1)
         zh_ptr, shared = self._grid(ck, "zh", zh, n, nL, None)
         pitchL = zh.stride(0) if (zh.dim() == 2 and n > 1) else nL
-        idx = self.empty(n, nG, dtype=torch.int32)
-        dims = _abi.Dims(n, nG, nL, nG, pitchGh, pitchL, shared, int(cols_per_block))
-        with torch.cuda.device(self.device):
-            rc = self._idx(ctypes.byref(dims), zh_ptr, Zh_ptr, idx.data_ptr(), _stream_ptr(stream, self.device))
-        _abi.check(self.lib, rc)
-        return idx
+        idx = out if out is not None else self.empty(n, nG, dtype=torch.int32)
+        if (idx.dtype != torch.int32 or idx.device != self.device or tuple(idx.shape) != (n, nG)
+                or (nG > 1 and idx.stride(1) != 1)):
+            raise ValueError("out must be int32 [%d x %d] on %s, contiguous along levels" % (n, nG, self.device))
+        pitchI = idx.stride(0) if n > 1 else nG
+        ck.keep.append(idx)
+        dims = _abi.Dims(n, nG, nL, pitchI, pitchGh, pitchL, shared, int(cols_per_block))
+        return CloudIndexPlan(self, self._idx, (ctypes.byref(dims), zh_ptr, Zh_ptr, idx.data_ptr()), ck.keep, {"idx": idx}, dims)
+
+    def cloud_indices(self, zh, Zh, stream=None, cols_per_block=0):
+        return self.plan_cloud_indices(zh, Zh, cols_per_block=cols_per_block).launch(stream)["idx"]
 
     # -- K3 ---------------------------------------------------------------------------------
     def plan_backward(self, gcm, zf, prof, factor, dt, Zf=None, *, want_start_index=True, conservative=False,
@@ -288,7 +333,7 @@ class Engine:
             a.start_index = ck.vec("out[start_index]", t, n, dtype=torch.int32)
             res["start_index"] = t
         dims = _abi.Dims(n, nG, nL, pitchG or nG, pitchGh or nG + 1, pitchL or nL, shared, int(cols_per_block))
-        return BackwardPlan(self, self._bwd, dims, a, ck.keep, res)
+        return BackwardPlan(self, self._bwd, (ctypes.byref(dims), ctypes.byref(a)), ck.keep, res, dims, a)
 
     def backward(self, *args, stream=None, **kw):
         return self.plan_backward(*args, **kw).launch(stream)
@@ -306,13 +351,15 @@ class Engine:
         return fp, bp
 
     # -- K5 ---------------------------------------------------------------------------------
-    def diagnostics(self, gcm, zf=None, prof=None, stream=None, cols_per_block=0):
+    def plan_diagnostics(self, gcm, zf=None, prof=None, out=None, cols_per_block=0):
         """spifs.nc diagnostics: Tv, THL, QT, Zf, Zh (splib/spcpl.py:176,197-198,214-215) and, when
-        ``zf``/``prof`` are given, pf, t, ql_water on LES levels (splib/spcpl.py:402,408-409)."""
+        ``zf``/``prof`` are given, pf, t, ql_water on LES levels (splib/spcpl.py:402,408-409).  Output tensors are
+        taken from ``out`` where given (views of a transfer buffer), else allocated ONCE here."""
         T_ = gcm["T"]
         n, nG = int(T_.shape[0]), int(T_.shape[1])
         ck = _Checker(self.device, self.dtype)
         a = _abi.DiagnosticsArgs()
+        out = dict(out or {})
         pitchG = pitchGh = pitchL = None
         for key, field in (("T", "T"), ("SH", "SH"), ("QL", "QL"), ("QI", "QI"), ("Pfull", "Pf"), ("Zgfull", "Zgfull")):
             ptr, pitchG = ck.mat("gcm[%s]" % key, gcm[key], n, nG, pitchG)
@@ -320,10 +367,12 @@ class Engine:
         a.Zghalf, pitchGh = ck.mat("gcm[Zghalf]", gcm["Zghalf"], n, nG + 1, pitchGh)
         res = {}
         for name in ("Tv", "THL", "QT", "Zf"):
-            res[name] = torch.empty(n, pitchG or nG, device=self.device, dtype=self.dtype)[:, :nG]
+            t = out.get(name)
+            res[name] = t if t is not None else torch.empty(n, pitchG or nG, device=self.device, dtype=self.dtype)[:, :nG]
             ptr, pitchG = ck.mat(name, res[name], n, nG, pitchG)
             setattr(a, name, ptr)
-        res["Zh"] = torch.empty(n, pitchGh or nG + 1, device=self.device, dtype=self.dtype)[:, :nG + 1]
+        t = out.get("Zh")
+        res["Zh"] = t if t is not None else torch.empty(n, pitchGh or nG + 1, device=self.device, dtype=self.dtype)[:, :nG + 1]
         a.Zh, pitchGh = ck.mat("Zh", res["Zh"], n, nG + 1, pitchGh)
         nL, shared = 1, 1
         if zf is not None and prof is not None:
@@ -333,14 +382,15 @@ class Engine:
                 setattr(a, field, ptr)
             a.zf, shared = self._grid(ck, "zf", zf, n, nL, pitchL)
             for name in ("pf", "t", "ql_water"):
-                res[name] = torch.empty(n, pitchL or nL, device=self.device, dtype=self.dtype)[:, :nL]
+                t = out.get(name)
+                res[name] = t if t is not None else torch.empty(n, pitchL or nL, device=self.device, dtype=self.dtype)[:, :nL]
                 ptr, pitchL = ck.mat(name, res[name], n, nL, pitchL)
                 setattr(a, name, ptr)
         dims = _abi.Dims(n, nG, nL, pitchG or nG, pitchGh or nG + 1, pitchL or nL, shared, int(cols_per_block))
-        with torch.cuda.device(self.device):
-            rc = self._diag(ctypes.byref(dims), ctypes.byref(a), _stream_ptr(stream, self.device))
-        _abi.check(self.lib, rc)
-        return res
+        return DiagnosticsPlan(self, self._diag, (ctypes.byref(dims), ctypes.byref(a)), ck.keep, res, dims, a)
+
+    def diagnostics(self, gcm, zf=None, prof=None, stream=None, cols_per_block=0):
+        return self.plan_diagnostics(gcm, zf, prof, cols_per_block=cols_per_block).launch(stream)
 
     # -- variability nudge (qt_forcing == 'variance') ------------------------------------------------
     def variability_nudge(self, qt, qsat, R, ql_av, qt_av, ql_ref, presf=None, thl=None, ql=None, constantT=False,
@@ -392,15 +442,19 @@ class Engine:
         return res
 
     # -- surface fluxes of columns without an LES -------------------------------------------------
-    def surface_fluxes(self, Ph_s, T_s, QLflux, QIflux, SHflux, TSflux, stream=None):
+    def plan_surface_fluxes(self, Ph_s, T_s, QLflux, QIflux, SHflux, TSflux, out=None):
         """(wthl, wqt) of spcpl.convert_surface_fluxes (splib/spcpl.py:153-161) for [n] scalars."""
         n = int(Ph_s.shape[0])
         ck = _Checker(self.device, self.dtype)
         ptrs = [ck.vec(nm, t, n) for nm, t in (("Ph_s", Ph_s), ("T_s", T_s), ("QLflux", QLflux), ("QIflux", QIflux),
                                                ("SHflux", SHflux), ("TSflux", TSflux))]
-        wthl, wqt = self.empty(n), self.empty(n)
+        out = dict(out or {})
+        wthl = out["wthl"] if "wthl" in out else self.empty(n)
+        wqt = out["wqt"] if "wqt" in out else self.empty(n)
+        optr = [ck.vec("wthl", wthl, n), ck.vec("wqt", wqt, n)]
         fn = getattr(self.lib, "spc_surface_fluxes_" + _DTYPES[self.dtype])
-        with torch.cuda.device(self.device):
-            rc = fn(n, *ptrs, wthl.data_ptr(), wqt.data_ptr(), _stream_ptr(stream, self.device))
-        _abi.check(self.lib, rc)
-        return wthl, wqt
+        return SurfacePlan(self, fn, [n] + ptrs + optr, ck.keep, {"wthl": wthl, "wqt": wqt})
+
+    def surface_fluxes(self, Ph_s, T_s, QLflux, QIflux, SHflux, TSflux, stream=None):
+        r = self.plan_surface_fluxes(Ph_s, T_s, QLflux, QIflux, SHflux, TSflux).launch(stream)
+        return r["wthl"], r["wqt"]

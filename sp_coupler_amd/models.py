@@ -37,7 +37,7 @@ class RequestsPool:
 
     def waitall(self):
         for r in self.requests:
-            if hasattr(r, "wait"):
+            if type(r) is not ImmediateRequest and hasattr(r, "wait"):
                 r.wait()
         self.requests = []
 
@@ -286,7 +286,8 @@ def make_models(n_les, npoints=None, nG=91, nL=160, seed=1):
 #         set_profile_tendencies(var, grid_indices, values[n x nG])
 #   LES   an ENSEMBLE object passed as `les_models` with batched = True, list-like over per-column LES objects:
 #         grid_indices, zf_cache, zh_cache, get_profiles_batched(keys, out), get_cloudfraction_batched(indices, out),
-#         set_forcings_batched(**arrays), evolve_model_batched(t)
+#         set_forcings_batched(**arrays), evolve_model_batched(t); for qt_forcing='variance' additionally
+#         get_fields_batched(name) -> [n x itot x jtot x ktot], set_fields_batched(name, array), model_time
 # ---------------------------------------------------------------------------------------------
 import time as _time
 
@@ -343,6 +344,15 @@ class BatchedSyntheticGCM(SyntheticGCM):
         self.model_time += self.dt
 
 
+class TimedSyntheticGCM(SyntheticGCM):
+    """SyntheticGCM with the reference's per-column protocol only, its methods counted in ``model_seconds``"""
+
+    get_profile_fields = _timed(SyntheticGCM.get_profile_fields)
+    get_surface_field = _timed(SyntheticGCM.get_surface_field)
+    set_profile_tendency = _timed(SyntheticGCM.set_profile_tendency)
+    evolve_model_from_cloud_scheme = _timed(SyntheticGCM.evolve_model_from_cloud_scheme)
+
+
 class _LESRow:
     """Per-column face of an ensemble row: the reference's per-LES method names on row i of the ensemble arrays."""
 
@@ -380,6 +390,7 @@ class _LESRow:
     def p(self):
         return {k: v[self._i] for k, v in self._e.p.items()}
 
+    @_timed
     def get_cloudfraction(self, indices, return_request=False):
         idx = numpy.clip(numpy.asarray(indices), 0, self._e.nL - 1)
         return _ret(self._e.A_lev[self._i][idx], return_request)
@@ -396,7 +407,7 @@ def _row_getter(key):
     def get(self, return_request=False):
         v = self._e.p[key][self._i]
         return _ret(v.copy() if isinstance(v, numpy.ndarray) else float(v), return_request)
-    return get
+    return _timed(get)
 
 
 def _row_setter(name):
@@ -408,7 +419,7 @@ def _row_setter(name):
         t[self._i] = v
         self.received.append(name)
         return _ret(None, return_request)
-    return set_
+    return _timed(set_)
 
 
 for _m, _k in (("get_profile_U", "U"), ("get_profile_V", "V"), ("get_profile_THL", "THL"), ("get_profile_QT", "QT"),
@@ -499,6 +510,21 @@ class SyntheticLESEnsemble:
         into the coupler's download buffer and are copied here"""
         for k, v in arrays.items():
             self.tend[_FORCING_SLOT[k]] = numpy.array(v, dtype=numpy.float64)
+
+    # -- optional: 3-D fields for qt_forcing='variance' (spcpl.variability_nudge_ensemble) ------------------------------
+    fields3d = None
+
+    def attach_fields(self, fields):
+        """``fields``: dict "Qsat", "QT", "THL", "QL" -> [n x itot x jtot x ktot] (what les.get_field returns, stacked)"""
+        self.fields3d = {k: numpy.array(v, dtype=numpy.float64) for k, v in fields.items()}
+
+    def get_fields_batched(self, name):
+        if self.fields3d is None:
+            raise NotImplementedError("this ensemble carries no 3-D fields (attach_fields)")
+        return self.fields3d[name].copy()
+
+    def set_fields_batched(self, name, values):
+        self.fields3d[name] = numpy.array(getattr(values, "number", values), dtype=numpy.float64)
 
     @_timed
     def evolve_model_batched(self, t):

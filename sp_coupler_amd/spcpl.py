@@ -30,7 +30,9 @@ import time
 import numpy
 import torch
 
+from . import transfer
 from .engine import Engine
+from .transfer import Arena, StepTrace  # noqa: F401  (re-exported: spcpl.Arena)
 
 log = logging.getLogger(__name__)
 
@@ -90,49 +92,11 @@ def _result(x):
     return x.result() if hasattr(x, "result") and callable(x.result) else x
 
 
-class Arena:
-    """Named arrays packed into ONE pinned host buffer and ONE device buffer, so that a whole group of inputs
-    (or results) crosses PCIe in a single copy.  ``h[name]`` / ``hn[name]`` are the host views (torch / NumPy),
-    ``d[name]`` the device views; every array starts 256-B aligned (the 16-B accesses of the compile-time-geometry
-    kernels need aligned bases).  With a CPU "device" (the test-only oracle engine) host and device are one buffer."""
-
-    ALIGN = 256
-
-    def __init__(self, device, specs):
-        self.device = torch.device(device)
-        off, lay = 0, []
-        for name, shape, dtype in specs:
-            nbytes = int(numpy.prod(shape, dtype=numpy.int64)) * torch.empty((), dtype=dtype).element_size()
-            lay.append((name, tuple(shape), dtype, off, nbytes))
-            off += -(-nbytes // self.ALIGN) * self.ALIGN
-        self.nbytes = off
-        on_gpu = self.device.type == "cuda"
-        self.host = torch.empty(max(off, 1), dtype=torch.uint8, pin_memory=on_gpu)
-        self.dev = torch.empty(max(off, 1), dtype=torch.uint8, device=self.device) if on_gpu else self.host
-        self.h, self.d, self.hn, self.end = {}, {}, {}, {}
-        for name, shape, dtype, o, nb in lay:
-            self.h[name] = self.host[o:o + nb].view(dtype).view(shape)
-            self.d[name] = self.dev[o:o + nb].view(dtype).view(shape)
-            self.hn[name] = self.h[name].numpy()
-            self.end[name] = o + nb
-
-    def upload(self, upto=None):
-        """host -> device (one async copy on the current stream; later kernels on that stream are ordered after it)"""
-        if self.dev is not self.host:
-            n = self.nbytes if upto is None else self.end[upto]
-            self.dev[:n].copy_(self.host[:n], non_blocking=True)
-
-    def download(self, upto=None):
-        """device -> host of the arrays up to and including ``upto`` (default all), then wait for it"""
-        if self.dev is not self.host:
-            n = self.nbytes if upto is None else self.end[upto]
-            self.host[:n].copy_(self.dev[:n], non_blocking=True)
-            torch.cuda.current_stream(self.device).synchronize()
-
-
 _F64, _I32 = torch.float64, torch.int32
 #: LES slab means the kernels consume (forward: spcpl.py:310-315; backward: spcpl.py:393-411); scalars last
-_LES_IN_LEVELS = ("U", "V", "THL", "QT", "QL", "T", "QL_ice")
+_LES_FWD_LEVELS = ("U", "V", "THL", "QT", "QL")
+_LES_BWD_LEVELS = ("T", "QL_ice")
+_LES_IN_LEVELS = _LES_FWD_LEVELS + _LES_BWD_LEVELS
 _LES_DIAG_LEVELS = ("Rhobf", "presf", "Rhof", "QR")          # conservative coarsening / spifs diagnostics only
 _LES_IN_SCALARS = ("PS", "Rain", "rain_last")
 
@@ -148,8 +112,11 @@ class StepBuffers:
         if with_surf:
             g += [(v, (n_total,), dt) for v in surf_vars]
         self.gcm_in = Arena(dev, g)
-        self.les_in = Arena(dev, [(k, (n, nL), dt) for k in _LES_IN_LEVELS] + [("A", (n, nG), dt)]
-                            + [(k, (n,), dt) for k in _LES_IN_SCALARS] + [(k, (n, nL), dt) for k in _LES_DIAG_LEVELS])
+        # upload order = order of need: what K1 reads (first step: only these are known), then what only K3 reads, then
+        # the diagnostics of conservative coarsening / spifs -- a copy "up to X" never carries more than it must
+        self.les_in = Arena(dev, [(k, (n, nL), dt) for k in _LES_FWD_LEVELS] + [(k, (n,), dt) for k in _LES_IN_SCALARS]
+                            + [(k, (n, nL), dt) for k in _LES_BWD_LEVELS] + [("A", (n, nG), dt)]
+                            + [(k, (n, nL), dt) for k in _LES_DIAG_LEVELS])
         # what the 7 LES setters + get_cloudfraction need comes first ("core": downloaded every step); heights
         # and surface fluxes follow and cross PCIe only when somebody asks for them
         self.fwd_out = Arena(dev, [(k, (n, nL), dt) for k in ("f_u", "f_v", "f_thl", "f_qt", "f_ql", "ql_ref")]
@@ -184,6 +151,7 @@ def _get_buffers(engine, n, n_total, nG, nL, with_surf):
         if len(_buffers) >= 4:      # a run has one geometry (plus spin-up variants): do not hoard pinned memory
             _buffers.clear()
         b = _buffers[key] = StepBuffers(engine, n, n_total, nG, nL, with_surf)
+        b.key = key
     return b
 
 
@@ -192,9 +160,64 @@ def _is_ensemble(les_models):
     return bool(getattr(les_models, "batched", False))
 
 
+class LazyRow:
+    """``les.gcm_Zf`` / ``les.gcm_Zh`` (splib/spcpl.py:200-201) of one column, computed on FIRST READ: the heights of a
+    step come from the diagnostics kernel K5 + one device->host copy for all columns, which a step whose caller never
+    looks at them does not pay.  Behaves like the float64 row it stands for (``numpy.asarray``, indexing, ``len``,
+    arithmetic, attribute access such as ``.shape`` / ``.number``); bound once to (batch, column) and valid for every
+    later step of that batch."""
+
+    __slots__ = ("_batch", "_key", "_i", "_step", "_v")
+
+    def __init__(self, batch, key, i):
+        self._batch, self._key, self._i, self._step, self._v = batch, key, i, -1, None
+
+    def _get(self):
+        b = self._batch
+        if self._step != b.step_id:
+            self._v = _wrap(self._key, _heights(b)[self._key][self._i])
+            self._step = b.step_id
+        return self._v
+
+    def __array__(self, dtype=None, copy=None):
+        a = numpy.asarray(_num(self._get()))
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def __getattr__(self, name):
+        return getattr(self._get(), name)
+
+    def __getitem__(self, k):
+        return self._get()[k]
+
+    def __len__(self):
+        return len(self._get())
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __repr__(self):
+        return "LazyRow(%s[%d]: %r)" % (self._key, self._i, self._get())
+
+
+def _lazy_binop(name):
+    def op(self, other):
+        return getattr(self._get(), name)(other._get() if isinstance(other, LazyRow) else other)
+    op.__name__ = name
+    return op
+
+
+for _n in ("add", "sub", "mul", "truediv", "pow", "radd", "rsub", "rmul", "rtruediv", "lt", "le", "gt", "ge", "eq", "ne"):
+    setattr(LazyRow, "__%s__" % _n, _lazy_binop("__%s__" % _n))
+LazyRow.__neg__ = lambda self: -self._get()
+LazyRow.__hash__ = None
+
+
 class ColumnBatch:
-    """All SP columns of one GCM step, resident in HBM as [n_cols x n_lev] tensors (views into the step's
-    transfer buffers: ONE host->device copy for the whole GCM state, one for the LES slab means)."""
+    """All SP columns of a run, resident in HBM as [n_cols x n_lev] tensors (views into the transfer buffers: ONE
+    host->device copy per step for the whole GCM state, one for the LES slab means).  The batch object PERSISTS across
+    steps while the set of LES objects, their GCM columns and the surface-coupling switch stay the same (``refill``
+    re-reads the GCM and resets the per-step results), so the per-LES handles (``les._spc_batch``, ``les._spc_row``, the
+    lazy ``les.gcm_Zf`` / ``gcm_Zh``) are attached once, not every step."""
 
     def __init__(self, engine, les_models, gcm, cols, extra_cols, couple_surface):
         self.engine = engine
@@ -203,8 +226,10 @@ class ColumnBatch:
         self.n = len(self.les_models)
         self.row = None if self.ens is not None else {id(les): i for i, les in enumerate(self.les_models)}
         self.extra_cols = list(extra_cols)
+        self.cols = list(cols)
+        self.couple_surface = bool(couple_surface)
         n_total = len(cols)
-        use_out = bool(getattr(gcm, "supports_out", False))
+        self.use_out = bool(getattr(gcm, "supports_out", False))
         first = None
         nL = self._les_levels()
         nG = getattr(gcm, "ktot", None)
@@ -213,6 +238,35 @@ class ColumnBatch:
             nG = first.shape[1]
         self.buf = b = _get_buffers(engine, self.n, n_total, int(nG), nL, couple_surface)
         hn = b.gcm_in.hn
+        self.gcm_host = {v: hn[v] for v in gcm_vars}      # rows n.. are the extra output columns
+        self.surf_host = {v: hn[v] for v in surf_vars} if couple_surface else {}
+        n = self.n
+        self.gcm = {k: t[:n] for k, t in b.gcm_in.d.items()}
+        self.profiles = {}                # id(les) -> profile dict (values or async requests)
+        self.profile_generation = 0
+        self.step_id = 0
+        self._reset_step()
+        self._fill(gcm, first)
+        if self.n:
+            self._pack_les_grid()
+
+    def _reset_step(self):
+        self.step_id += 1
+        self.fwd = None                   # host results of the last forward launch
+        self.fwd_key = self.fwd_raw = None
+        self.fwd_rows = None              # per-LES protocol: row views of this step's snapshot of the forward results
+        self.fwd_written = False
+        self.bwd = None
+        self.bwd_key = self.bwd_raw = None
+        self.bwd_rows = None
+        self.dev_prof = None              # device views of the LES slab means uploaded for this step
+        self.diag_host = self.conv = self.idx_host = self.idx_rows = None
+        self.wlp = self.wlp_key = None
+        self.ql_ref_host = None
+
+    def _fill(self, gcm, first=None):
+        """one ``get_profile_fields`` per variable straight into the pinned buffer, ONE host->device copy (spcpl.py:62-75)"""
+        hn, cols, use_out = self.buf.gcm_in.hn, self.cols, self.use_out
         for v in gcm_vars:                                                    # spcpl.py:62-67
             if v == gcm_vars[0] and first is not None:
                 numpy.copyto(hn[v], first)
@@ -220,26 +274,33 @@ class ColumnBatch:
                 gcm.get_profile_fields(v, cols, out=hn[v])
             else:
                 numpy.copyto(hn[v], _num(gcm.get_profile_fields(v, cols)))
-        if couple_surface:
+        if self.couple_surface:
             for v in surf_vars:                                               # spcpl.py:69-75
                 if use_out:
                     gcm.get_surface_field(v, cols, out=hn[v])
                 else:
                     numpy.copyto(hn[v], _num(gcm.get_surface_field(v, cols)))
-        b.gcm_in.upload()
-        self.gcm_host = {v: hn[v] for v in gcm_vars}      # rows n.. are the extra output columns
-        self.surf_host = {v: hn[v] for v in surf_vars} if couple_surface else {}
-        n = self.n
-        self.gcm = {k: t[:n] for k, t in b.gcm_in.d.items()}
-        self.profiles = {}                # id(les) -> profile dict (values or async requests)
-        self.profile_generation = 0
-        self.fwd = None                   # host results of the last forward launch
-        self.fwd_key = None
-        self.bwd = None
-        self.bwd_key = None
-        self.dev_prof = None              # device views of the LES slab means uploaded for this step
-        if self.n:
-            self._pack_les_grid()
+        self.buf.gcm_in.upload(what="h2d_gcm")
+
+    def reusable_for(self, engine, les_models, cols, couple_surface):
+        """same engine, same LES objects in the same order, same GCM columns, same surface switch, buffers still ours"""
+        if engine is not self.engine or bool(couple_surface) != self.couple_surface or cols != self.cols:
+            return False
+        if _buffers.get(self.buf.key) is not self.buf:
+            return False
+        if self.ens is not None:
+            return les_models is self.ens
+        if _is_ensemble(les_models) or len(les_models) != self.n:
+            return False
+        mine = self.les_models
+        return all(a is b for a, b in zip(les_models, mine))
+
+    def refill(self, gcm):
+        """next step of the same batch: per-step results dropped, GCM state re-read and uploaded.  The slab means
+        fetched by get_les_profiles() after the previous LES run stay (``profiles``)."""
+        self.use_out = bool(getattr(gcm, "supports_out", False))
+        self._reset_step()
+        self._fill(gcm)
 
     def _les_levels(self):
         if not len(self.les_models):
@@ -248,7 +309,7 @@ class ColumnBatch:
         return int(_num(z).shape[-1])
 
     def _pack_les_grid(self):
-        """les.zf_cache / les.zh_cache (splib/splib.py:152-153): one shared [nL] grid when all LES
+        """les.zf_cache / les.zh_cache (splib/splib.py:152-153, set once per LES): one shared [nL] grid when all LES
         instances agree (the normal case), else [n x nL]."""
         if self.ens is not None:
             zf_host, zh_host = _num(self.ens.zf_cache), _num(self.ens.zh_cache)
@@ -262,27 +323,56 @@ class ColumnBatch:
         self.buf.set_grid(zf_host, zh_host)
         self.zf, self.zh, self.zf_host, self.zh_host = self.buf.zf, self.buf.zh, self.buf.zf_host, self.buf.zh_host
 
+    def attach(self, attach_rows=False):
+        """hand every LES object its handles (once per batch; the reference scatters rows here, spcpl.py:81-86)"""
+        if self.ens is not None:
+            self.ens._spc_batch = self
+            return
+        for i, les in enumerate(self.les_models):
+            les._spc_batch, les._spc_row = self, i
+            les.gcm_Zf, les.gcm_Zh = LazyRow(self, "Zf", i), LazyRow(self, "Zh", i)         # spcpl.py:200-201, on first read
+        if attach_rows:
+            self.attach_gcm_rows()
+
+    def attach_gcm_rows(self):
+        for i, les in enumerate(self.les_models):
+            for v in gcm_vars:
+                setattr(les, v, self.gcm_host[v][i].copy())
+            for v in self.surf_host:
+                setattr(les, v, self.surf_host[v][i])
+
     def index_of(self, les):
         if self.ens is not None:
             return les._i
         return self.row[id(les)]
 
     # ---- LES slab means -> device -------------------------------------------------------------
-    def stack_profiles(self, keys, source):
-        """per-LES protocol: source(les) -> dict (values or async requests).  Rows are written straight into the
-        pinned upload buffer; ONE host->device copy for all keys.  Returns dict key -> device tensor."""
+    def stack_profiles(self, keys, source, upto=None):
+        """per-LES protocol: source(les) -> dict (values, AMUSE-style quantities or async requests).  Rows are written
+        straight into the pinned upload buffer (one C loop per variable; the kind of value -- request / quantity / bare
+        array -- is looked at on the FIRST column only); ONE host->device copy for all keys."""
         hn = self.buf.les_in.hn
         rows = [source(les) for les in self.les_models]
         for k in keys:
-            vals = [_num(_result(r[k])) for r in rows]
-            if hn[k].ndim == 2:
-                numpy.stack(vals, out=hn[k])          # one C loop per variable, straight into pinned memory
+            vals = [r[k] for r in rows]
+            v0 = vals[0]
+            if hasattr(v0, "result") and callable(v0.result):
+                vals = [v.result() for v in vals]
+                v0 = vals[0]
+            if hasattr(v0, "number"):
+                vals = [v.number for v in vals]
+            dst = hn[k]
+            if dst.ndim == 2:
+                try:
+                    numpy.concatenate(vals, out=dst.reshape(-1))      # n rows of nL float64 -> the [n x nL] block
+                except (TypeError, ValueError):                       # mixed dtypes / shapes: the careful way
+                    numpy.stack([numpy.asarray(v, dtype=numpy.float64) for v in vals], out=dst)
             else:
-                hn[k][:] = vals
-        self.buf.les_in.upload()
+                dst[:] = vals
+        self.buf.les_in.upload(upto=upto, what="h2d_les")
         return {k: self.buf.les_in.d[k] for k in keys}
 
-    def upload_profiles(self, keys, arrays=None):
+    def upload_profiles(self, keys, arrays=None, upto=None):
         """batched protocol: ``arrays`` (dict key -> [n x ...]) are copied into the upload buffer unless they ARE its
         views already (ensemble getters write there directly); one host->device copy."""
         hn = self.buf.les_in.hn
@@ -290,7 +380,7 @@ class ColumnBatch:
             for k in keys:
                 if arrays[k] is not hn[k]:
                     numpy.copyto(hn[k], _num(arrays[k]))
-        self.buf.les_in.upload()
+        self.buf.les_in.upload(upto=upto, what="h2d_les")
         return {k: self.buf.les_in.d[k] for k in keys}
 
 
@@ -326,21 +416,20 @@ def gather_gcm_data(gcm, les_models, couple_surface, output_column_indices=None,
     if not any(cols):                                                        # quirk kept: spcpl.py:63,71
         _current = None
         return None
-    batch = ColumnBatch(get_engine(), les_models, gcm, cols, extra_cols, couple_surface)
+    eng = get_engine()
+    prev = _current
+    if prev is not None and prev.reusable_for(eng, les_models, cols, couple_surface):
+        batch = prev                                     # same columns as last step: handles stay, buffers are refilled
+        batch.refill(gcm)
+        if attach_rows and batch.ens is None:
+            batch.attach_gcm_rows()
+    else:
+        batch = ColumnBatch(eng, les_models, gcm, cols, extra_cols, couple_surface)
+        if prev is not None and batch.row is not None:   # slab means fetched by get_les_profiles() after the previous LES run
+            batch.profiles = {k: v for k, v in prev.profiles.items() if k in batch.row}
+        batch.attach(attach_rows)
     log.info("Fetching gcm data took %d s" % (time.time() - start))
     profile_data, surface_data = batch.gcm_host, batch.surf_host
-    if _current is not None and batch.row is not None:   # slab means fetched by get_les_profiles() after the previous LES run
-        batch.profiles = {k: v for k, v in _current.profiles.items() if k in batch.row}
-    if ens is not None:
-        ens._spc_batch = batch
-    else:
-        for i, les in enumerate(les_models):
-            les._spc_batch = batch
-            if attach_rows:
-                for v in gcm_vars:
-                    setattr(les, v, profile_data[v][i].copy())
-                for v in surface_data:
-                    setattr(les, v, surface_data[v][i])
     # extra output columns: spcpl.py:89-129
     if extra_cols and write and writer is not None:
         n0 = batch.n
@@ -366,6 +455,7 @@ def gather_gcm_data(gcm, les_models, couple_surface, output_column_indices=None,
 _FWD_KEYS = ("U", "V", "THL", "QT", "QL", "PS", "Rain")
 _FWD_CORE = ("f_u", "f_v", "f_thl", "f_qt", "f_ql", "ql_ref", "f_ps", "idx")
 _FWD_SURF = ("z0m", "z0h", "wthl", "wqt")
+_DIAG_GCM = ("Zf", "Zh", "Tv", "THL", "QT")       # K5's GCM-level outputs; contiguous in StepBuffers.fwd_out
 
 
 def _first_step_profile(les):
@@ -377,12 +467,21 @@ def _first_step_profile(les):
 
 def _plan(batch, kind, flags, make):
     """launch plan of this batch geometry, built once and reused every step (the tensors it binds are views into
-    the StepBuffers, which persist); the test-only oracle engine has no plans and is called directly"""
+    the StepBuffers, which persist)"""
     key = (kind,) + tuple(flags)
     plan = batch.buf.plans.get(key)
     if plan is None:
         plan = batch.buf.plans[key] = make()
     return plan
+
+
+def _launch(batch, plan, what):
+    if transfer.trace is not None:
+        with transfer.trace.region(what, 0, batch.engine.device):
+            plan.launch()
+    else:
+        plan.launch()
+    return plan.outputs
 
 
 def forward_batched(batch, profiles, dt_gcm, factor, couple_surface=False):
@@ -392,23 +491,17 @@ def forward_batched(batch, profiles, dt_gcm, factor, couple_surface=False):
     into the pinned download buffer, filled by ONE device->host copy."""
     eng, b = batch.engine, batch.buf
     dt = float(_num(dt_gcm))
-    keys = _FWD_CORE + (_FWD_SURF if couple_surface else ())
     # the surface outputs live behind idx in the buffer; z0m / z0h are pass-throughs written by the kernel too
     out = {k: b.fwd_out.d[k] for k in _FWD_CORE}
     prof = {k: profiles[k] for k in ("U", "V", "THL", "QT", "QL", "PS")}
     if couple_surface:
         out.update(wthl=b.fwd_out.d["wthl"], wqt=b.fwd_out.d["wqt"])
-    if hasattr(eng, "plan_forward"):
-        plan = _plan(batch, "fwd", (bool(couple_surface),), lambda: eng.plan_forward(
-            batch.gcm, batch.zf, prof, float(factor), dt, zh=batch.zh, want_profiles=False, want_heights=False,
-            couple_surface=couple_surface, out=out))
-        plan.args.factor, plan.args.dt = float(factor), dt
-        plan.launch()
-        res = plan.outputs
-    else:
-        res = eng.forward(batch.gcm, batch.zf, prof, float(factor), dt, zh=batch.zh, want_profiles=False,
-                          want_heights=False, couple_surface=couple_surface, out=out)
-    b.fwd_out.download(upto="wqt" if couple_surface else "idx")
+    plan = _plan(batch, "fwd", (bool(couple_surface),), lambda: eng.plan_forward(
+        batch.gcm, batch.zf, prof, float(factor), dt, zh=batch.zh, want_profiles=False, want_heights=False,
+        couple_surface=couple_surface, out=out))
+    plan.set_scalars(float(factor), dt)
+    res = _launch(batch, plan, "k1")
+    b.fwd_out.download(upto="wqt" if couple_surface else "idx", what="d2h_forcings")
     host = {k: b.fwd_out.hn[k] for k in _FWD_CORE}
     if couple_surface:
         host["wthl"], host["wqt"] = b.fwd_out.hn["wthl"], b.fwd_out.hn["wqt"]
@@ -419,10 +512,16 @@ def forward_batched(batch, profiles, dt_gcm, factor, couple_surface=False):
 
 
 def _heights(batch):
-    """Zf, Zh (+ Tv, THL, QT) of every column on the host: K5 on the batch, fetched only when somebody needs
-    them (les.gcm_Zf / gcm_Zh of the per-LES API, the spifs writer); spcpl.py:176, 197-198, 214-215."""
-    if getattr(batch, "diag_host", None) is None:
-        batch.diag_host = {k: v.cpu().numpy() for k, v in batch.engine.diagnostics(batch.gcm).items()}
+    """Zf, Zh (+ Tv, THL, QT) of every column on the host: K5 on the batch (cached launch plan writing into the step's
+    download buffer, one device->host copy of that span), run only when somebody needs them (a read of les.gcm_Zf /
+    gcm_Zh, the spifs writer); spcpl.py:176, 197-198, 214-215."""
+    if batch.diag_host is None:
+        b = batch.buf
+        plan = _plan(batch, "diag", (), lambda: batch.engine.plan_diagnostics(
+            batch.gcm, out={k: b.fwd_out.d[k] for k in _DIAG_GCM}))
+        _launch(batch, plan, "k5")
+        b.fwd_out.download(upto=_DIAG_GCM[-1], start=_DIAG_GCM[0], what="d2h_heights")
+        batch.diag_host = {k: numpy.array(b.fwd_out.hn[k]) for k in _DIAG_GCM}
     return batch.diag_host
 
 
@@ -432,30 +531,51 @@ def _finish_forward(batch, host, rain, rain_last, dt_gcm):
     host["rainrate"] = (host["rain"] - rain_last) / dt                        # spcpl.py:325 (IEEE: same on host)
     batch.fwd = host
     batch.fwd_written = False
+    batch.fwd_rows = None
     return host
 
 
 def _ensure_forward(batch, les, firststep, profile, dt_gcm, factor, couple_surface):
     key = (batch.profile_generation, bool(firststep), float(_num(dt_gcm)), float(factor), bool(couple_surface))
-    if batch.fwd is not None and batch.fwd_key == key:
-        return batch.fwd
-    if firststep:
-        src = _first_step_profile
-    else:
-        if profile is not None:
-            batch.profiles.setdefault(id(les), profile)
-        missing = [m for m in batch.les_models if id(m) not in batch.profiles]
-        if missing:
-            raise RuntimeError("set_les_forcings: LES profiles of %d columns are unknown; call get_les_profiles() "
-                               "for every LES after stepping it (as splib.step_les_models does) or use "
-                               "set_les_forcings_batched()" % len(missing))
-        src = lambda m: batch.profiles[id(m)]               # noqa: E731
-    prof = batch.stack_profiles(_FWD_KEYS, src)
-    rain_last = numpy.array([float(_num(getattr(m, "rain", 0.0))) for m in batch.les_models])   # spcpl.py:316-319
-    host = forward_batched(batch, prof, dt_gcm, factor, couple_surface)
-    _finish_forward(batch, host, batch.buf.les_in.hn["Rain"], rain_last, dt_gcm)
-    batch.fwd_key = key
+    if batch.fwd is None or batch.fwd_key != key:
+        if firststep:
+            src = _first_step_profile
+        else:
+            if profile is not None:
+                batch.profiles.setdefault(id(les), profile)
+            missing = [m for m in batch.les_models if id(m) not in batch.profiles]
+            if missing:
+                raise RuntimeError("set_les_forcings: LES profiles of %d columns are unknown; call get_les_profiles() "
+                                   "for every LES after stepping it (as splib.step_les_models does) or use "
+                                   "set_les_forcings_batched()" % len(missing))
+            src = lambda m: batch.profiles[id(m)]               # noqa: E731
+        prof = batch.stack_profiles(_FWD_KEYS, src, upto="Rain")
+        rain_last = numpy.array([float(_num(getattr(m, "rain", 0.0))) for m in batch.les_models])   # spcpl.py:316-319
+        host = forward_batched(batch, prof, dt_gcm, factor, couple_surface)
+        _finish_forward(batch, host, batch.buf.les_in.hn["Rain"], rain_last, dt_gcm)
+        batch.fwd_key = key
+    # the per-LES loop passes the SAME objects for every column of a step: later calls recognise them by identity
+    batch.fwd_raw = (firststep, dt_gcm, factor, couple_surface, batch.profile_generation)
     return batch.fwd
+
+
+def _rows_of(block):
+    """fresh copy of a [n x m] (or [n]) result block and the list of its rows: what the per-LES setters receive.  A
+    model may keep the array it is handed -- it never aliases a transfer buffer a later step overwrites -- and the
+    whole block is copied ONCE per step instead of once per column and variable."""
+    return list(numpy.array(block))
+
+
+def _forward_rows(batch):
+    f = batch.fwd
+    rows = [_rows_of(f[k]) for k in ("f_u", "f_v", "f_thl", "f_qt", "f_ps", "f_ql", "ql_ref", "rain")]
+    if "wthl" in f:
+        rows += [_rows_of(f[k]) for k in _FWD_SURF]
+    if _unit_wrapper is not None:
+        names = ("f_u", "f_v", "f_thl", "f_qt", "f_ps", "f_ql", "ql_ref", None) + _FWD_SURF
+        rows = [r if nm is None else [_unit_wrapper(nm, v) for v in r] for nm, r in zip(names, rows)]
+    batch.fwd_rows = rows
+    return rows
 
 
 def _write_forward(batch):
@@ -478,7 +598,7 @@ def convert_profiles(les, write=True):
     """splib/spcpl.py:171-246: (u, v, thl, qt, ps, ql) for one column; caches les.gcm_Zf / gcm_Zh."""
     batch = _batch_of(les)
     i = batch.index_of(les)
-    if getattr(batch, "conv", None) is None:
+    if batch.conv is None:
         eng = batch.engine
         nL = batch.zf.shape[-1]
         z = torch.zeros(batch.n, nL, device=eng.device, dtype=eng.dtype)
@@ -496,33 +616,38 @@ def set_les_forcings(les, gcm, asynchronous, firststep, profile, dt_gcm, factor,
                      write=True, variability_nudge_constant_T=False):
     """splib/spcpl.py:299-385. The first call of a step computes the forcings of ALL columns in one
     launch; this call then pushes column ``les``'s rows to its setters and returns the request dict."""
-    batch = _batch_of(les)
-    f = _ensure_forward(batch, les, firststep, profile, dt_gcm, factor, couple_surface)
-    i = batch.index_of(les)
-    d = _heights(batch)
-    les.gcm_Zf, les.gcm_Zh = _wrap("Zf", d["Zf"][i]), _wrap("Zh", d["Zh"][i])   # spcpl.py:200-201
-    les.rain = f["rain"][i]                                                  # spcpl.py:324
-    row = lambda k: f[k][i].copy()              # noqa: E731  (f[...] are views of a buffer the next step overwrites)
+    try:
+        batch, i = les._spc_batch, les._spc_row
+    except AttributeError:                       # a per-column face of an ensemble, or gather_gcm_data() not called
+        batch = _batch_of(les)
+        i = batch.index_of(les)
+    raw = batch.fwd_raw
+    if (raw is None or raw[0] is not firststep or raw[1] is not dt_gcm or raw[2] is not factor
+            or raw[3] is not couple_surface or raw[4] != batch.profile_generation):
+        _ensure_forward(batch, les, firststep, profile, dt_gcm, factor, couple_surface)
+    rows = batch.fwd_rows or _forward_rows(batch)
+    les.rain = rows[7][i]                                                    # spcpl.py:324
+    ql_ref = rows[6][i]
     req = {
-        "U": les.set_tendency_U(_wrap("f_u", row("f_u")), return_request=asynchronous),                 # :341
-        "V": les.set_tendency_V(_wrap("f_v", row("f_v")), return_request=asynchronous),                 # :342
-        "THL": les.set_tendency_THL(_wrap("f_thl", row("f_thl")), return_request=asynchronous),         # :343
-        "QT": les.set_tendency_QT(_wrap("f_qt", row("f_qt")), return_request=asynchronous),             # :344
-        "SP": les.set_tendency_surface_pressure(_wrap("f_ps", f["f_ps"][i]), return_request=asynchronous),  # :345
-        "QL": les.set_tendency_QL(_wrap("f_ql", row("f_ql")), return_request=asynchronous),             # :346
-        "QLp": les.set_ref_profile_QL(_wrap("ql_ref", row("ql_ref")), return_request=asynchronous),     # :347
+        "U": les.set_tendency_U(rows[0][i], return_request=asynchronous),                  # spcpl.py:341
+        "V": les.set_tendency_V(rows[1][i], return_request=asynchronous),                  # :342
+        "THL": les.set_tendency_THL(rows[2][i], return_request=asynchronous),              # :343
+        "QT": les.set_tendency_QT(rows[3][i], return_request=asynchronous),                # :344
+        "SP": les.set_tendency_surface_pressure(rows[4][i], return_request=asynchronous),  # :345
+        "QL": les.set_tendency_QL(rows[5][i], return_request=asynchronous),                # :346
+        "QLp": les.set_ref_profile_QL(ql_ref, return_request=asynchronous),                # :347
     }
-    les.ql_ref = _wrap("ql_ref", row("ql_ref"))                              # spcpl.py:348
+    les.ql_ref = ql_ref                                                      # spcpl.py:348
     if write and writer is not None and not batch.fwd_written:
         _write_forward(batch)                    # once per launch, for all columns
     if couple_surface:                                                       # spcpl.py:359-364
-        req["Z0M_surf"] = les.set_z0m_surf(_wrap("z0m", f["z0m"][i]), return_request=asynchronous)
-        req["Z0H_surf"] = les.set_z0h_surf(_wrap("z0h", f["z0h"][i]), return_request=asynchronous)
-        req["WT_surf"] = les.set_wt_surf(_wrap("wthl", f["wthl"][i]), return_request=asynchronous)
-        req["WQ_surf"] = les.set_wq_surf(_wrap("wqt", f["wqt"][i]), return_request=asynchronous)
+        req["Z0M_surf"] = les.set_z0m_surf(rows[8][i], return_request=asynchronous)
+        req["Z0H_surf"] = les.set_z0h_surf(rows[9][i], return_request=asynchronous)
+        req["WT_surf"] = les.set_wt_surf(rows[10][i], return_request=asynchronous)
+        req["WQ_surf"] = les.set_wq_surf(rows[11][i], return_request=asynchronous)
     if qt_forcing == 'variance':                                             # spcpl.py:377-382
         if float(_num(les.get_model_time())) > 0:
-            variability_nudge(les, dt_gcm, variability_nudge_constant_T, write=write)
+            variability_nudge(les, dt_gcm, variability_nudge_constant_T)     # (the reference does not pass `write` on)
     return req
 
 
@@ -539,14 +664,15 @@ def set_les_forcings_batched(les_models, gcm, asynchronous, firststep, profiles,
                                   variability_nudge_constant_T)
     batch = _batch_of(les_models[0])
     if not firststep:
+        reg = batch.profiles
         for les in les_models:
-            batch.profiles[id(les)] = profiles[les]
-    reqs = [set_les_forcings(les, gcm, asynchronous, firststep, None if firststep else profiles[les], dt_gcm, factor,
-                             couple_surface, 'sp', write) for les in les_models]
+            reg[id(les)] = profiles[les]
+    reqs = [set_les_forcings(les, gcm, asynchronous, firststep, None, dt_gcm, factor, couple_surface, 'sp', write)
+            for les in les_models]
     if qt_forcing == 'variance':       # spcpl.py:377-382, for all LES in one launch (R drawn in the same les order)
         started = [les for les in les_models if float(_num(les.get_model_time())) > 0]
         if started:
-            variability_nudge_batched(started, dt_gcm, variability_nudge_constant_T, write=write)
+            variability_nudge_batched(started, dt_gcm, variability_nudge_constant_T)
     return reqs
 
 
@@ -556,9 +682,12 @@ def _ensemble_forcings(ens, firststep, profiles, dt_gcm, factor, couple_surface,
     batch = _batch_of(ens)
     b = batch.buf
     hn = b.les_in.hn
+    if qt_forcing == 'variance' and not hasattr(ens, "get_fields_batched"):
+        raise NotImplementedError("qt_forcing='variance' needs the 3-D LES fields: an ensemble must offer get_fields_batched / "
+                                  "set_fields_batched (sp_coupler_amd.models docstring), or pass the LES objects as a plain list")
     if firststep:                                                            # spcpl.py:302-308, 321
         ens.get_profiles_batched(_FWD_KEYS, {k: hn[k] for k in _FWD_KEYS})
-        b.les_in.upload()
+        b.les_in.upload(upto="Rain", what="h2d_les")
         b.rain_prev = numpy.zeros(batch.n)                                   # `except: rain_last = 0`, spcpl.py:316-319
     elif profiles is None or profiles.get("_buffers") is not b:
         raise RuntimeError("set_les_forcings_batched: pass what get_les_profiles_batched() returned after the last "
@@ -567,7 +696,7 @@ def _ensemble_forcings(ens, firststep, profiles, dt_gcm, factor, couple_surface,
     host = forward_batched(batch, dev, dt_gcm, factor, couple_surface)
     _finish_forward(batch, host, hn["Rain"], getattr(b, "rain_prev", numpy.zeros(batch.n)), dt_gcm)
     b.rain_prev = host["rain"]                                               # les.rain = rain, spcpl.py:324
-    batch.ql_ref_host = host["ql_ref"]
+    batch.ql_ref_host = ens.ql_ref = host["ql_ref"]                          # les.ql_ref = ql, spcpl.py:348
     kw = dict(U=host["f_u"], V=host["f_v"], THL=host["f_thl"], QT=host["f_qt"], SP=host["f_ps"], QL=host["f_ql"],
               QLp=host["ql_ref"])                                            # spcpl.py:341-347
     if couple_surface:                                                       # spcpl.py:359-364
@@ -576,7 +705,7 @@ def _ensemble_forcings(ens, firststep, profiles, dt_gcm, factor, couple_surface,
     if write and writer is not None:
         _write_forward(batch)
     if qt_forcing == 'variance' and float(_num(ens.model_time)) > 0:         # spcpl.py:377-382
-        variability_nudge_batched(list(ens), dt_gcm, constant_T, write=write)
+        variability_nudge_ensemble(ens, dt_gcm, constant_T)
     return []
 
 
@@ -624,21 +753,27 @@ def _index_map(batch):
     the fused K2 output of this step's forward launch, or the standalone K2 before any forward ran"""
     if batch.fwd is not None and "idx" in batch.fwd:
         return batch.fwd["idx"]
-    if getattr(batch, "idx_host", None) is None:
-        d = _heights(batch)
-        Zh = torch.from_numpy(d["Zh"]).to(batch.engine.device, batch.engine.dtype)
-        batch.idx_host = batch.engine.cloud_indices(batch.zh, Zh).cpu().numpy()
+    if batch.idx_host is None:
+        _heights(batch)                                   # K5 left Zh of this step in the download buffer's device side
+        b = batch.buf
+        plan = _plan(batch, "idx", (), lambda: batch.engine.plan_cloud_indices(batch.zh, b.fwd_out.d["Zh"], out=b.fwd_out.d["idx"]))
+        _launch(batch, plan, "k2")
+        b.fwd_out.download(upto="idx", start="idx", what="d2h_idx")
+        batch.idx_host = numpy.array(b.fwd_out.hn["idx"])
     return batch.idx_host
+
+
+def _index_rows(batch):
+    rows = batch.idx_rows
+    if rows is None or rows[0] is not batch.fwd:
+        rows = batch.idx_rows = (batch.fwd, _rows_of(_index_map(batch)))
+    return rows[1]
 
 
 def cloud_fraction_indices(les):
     """indices = searchsorted(zh, Zh, side='right')[:-1][::-1]  (splib/spcpl.py:26 / 764), from K2"""
     batch = _batch_of(les)
-    i = batch.index_of(les)
-    if batch.fwd is None:        # before any forward launch of this step: heights as convert_profiles caches them
-        d = _heights(batch)
-        les.gcm_Zf, les.gcm_Zh = _wrap("Zf", d["Zf"][i]), _wrap("Zh", d["Zh"][i])       # spcpl.py:200-201
-    return _index_map(batch)[i].copy()
+    return _index_rows(batch)[batch.index_of(les)]
 
 
 def get_cloud_fraction(les):
@@ -650,7 +785,13 @@ def get_cloud_fraction(les):
 def get_les_profiles(les, asynchronous):
     """splib/spcpl.py:747-767: 14 getters; the index map comes from the GPU (K2). The returned dict is
     also remembered so that the next forward / backward launch can batch all columns."""
-    indices = cloud_fraction_indices(les)
+    try:
+        batch, i = les._spc_batch, les._spc_row
+    except AttributeError:
+        batch = _batch_of(les)
+        i = batch.index_of(les)
+    rows = batch.idx_rows
+    indices = (rows[1] if rows is not None and rows[0] is batch.fwd else _index_rows(batch))[i]
     prof = {"U": les.get_profile_U(return_request=asynchronous), "V": les.get_profile_V(return_request=asynchronous),
             "presf": les.get_presf(return_request=asynchronous), "Rhof": les.get_rhof(return_request=asynchronous),
             "Rhobf": les.get_rhobf(return_request=asynchronous), "THL": les.get_profile_THL(return_request=asynchronous),
@@ -660,12 +801,13 @@ def get_les_profiles(les, asynchronous):
             "PS": les.get_surface_pressure(return_request=asynchronous), "T": les.get_profile_T(return_request=asynchronous),
             "A": les.get_cloudfraction(indices, return_request=asynchronous),
             "Rain": les.get_rain(return_request=asynchronous)}
-    batch = _batch_of(les)
-    if id(les) in batch.profiles and len(batch.profiles) >= batch.n:
-        batch.profiles = {}
-    if not batch.profiles:
+    reg = batch.profiles
+    key = id(les)
+    if key in reg and len(reg) >= batch.n:       # a new round of fetches begins (every column has been seen once)
+        reg = batch.profiles = {}
+    if not reg:
         batch.profile_generation += 1
-    batch.profiles[id(les)] = prof
+    reg[key] = prof
     return prof
 
 
@@ -683,7 +825,7 @@ def get_les_profiles_batched(les_models, asynchronous=False, diagnostics=False):
     keys = _LES_IN_LEVELS + ("PS", "Rain") + (_LES_DIAG_LEVELS if diagnostics else ())
     ens.get_profiles_batched(keys, {k: hn[k] for k in keys})
     ens.get_cloudfraction_batched(_index_map(batch), hn["A"])                 # spcpl.py:761-765
-    b.les_in.upload()
+    b.les_in.upload(upto=None if diagnostics else "A", what="h2d_les")        # the diagnostics sit at the end
     batch.profile_generation += 1
     prof = {k: hn[k] for k in keys + ("A",)}
     prof["_buffers"] = b
@@ -695,6 +837,7 @@ def get_les_profiles_batched(les_models, asynchronous=False, diagnostics=False):
 # ---------------------------------------------------------------------------------------------
 _BWD_KEYS = ("T", "QT", "QL", "QL_ice", "U", "V", "A")
 _BWD_OUT = ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A")
+_TEND_VARS = ("U", "V", "T", "SH", "QL", "QI", "A")                            # setter order of spcpl.py:535-542
 
 
 def backward_batched(batch, profiles, dt_gcm, factor=1, conservative=False):
@@ -707,21 +850,16 @@ def backward_batched(batch, profiles, dt_gcm, factor=1, conservative=False):
     out = {k: b.bwd_out.d[k] for k in _BWD_OUT}
     out["start_index"] = b.bwd_out.d["start_index"]
     prof = {k: profiles[k] for k in _BWD_KEYS + (("Rhobf",) if conservative else ())}
-    if hasattr(eng, "plan_backward"):
-        plan = _plan(batch, "bwd", (bool(conservative),), lambda: eng.plan_backward(
-            batch.gcm, batch.zf, prof, float(factor), dt, Zf=None, conservative=conservative, zh=batch.zh, out=out))
-        plan.args.factor, plan.args.dt = float(factor), dt
-        plan.launch()
-    else:
-        eng.backward(batch.gcm, batch.zf, prof, float(factor), dt, Zf=None, conservative=conservative, zh=batch.zh, out=out)
-    b.bwd_out.download()
+    plan = _plan(batch, "bwd", (bool(conservative),), lambda: eng.plan_backward(
+        batch.gcm, batch.zf, prof, float(factor), dt, Zf=None, conservative=conservative, zh=batch.zh, out=out))
+    plan.set_scalars(float(factor), dt)
+    _launch(batch, plan, "k4" if conservative else "k3")
+    b.bwd_out.download(what="d2h_tendencies")
+    batch.bwd_rows = None
     return {k: b.bwd_out.hn[k] for k in _BWD_OUT + ("start_index",)}
 
 
-def set_gcm_tendencies(gcm, les, profile, dt_gcm, factor=1, write=True, conservative=False):
-    """splib/spcpl.py:388-555. First call of a step: ONE launch for all columns; every call: the seven
-    ``gcm.set_profile_tendency`` setters for column ``les`` (spcpl.py:535-542)."""
-    batch = _batch_of(les)
+def _ensure_backward(batch, les, profile, dt_gcm, factor, write, conservative):
     key = (batch.profile_generation, float(_num(dt_gcm)), float(factor), bool(conservative))
     if batch.bwd is None or batch.bwd_key != key:
         if profile is not None:
@@ -730,17 +868,50 @@ def set_gcm_tendencies(gcm, les, profile, dt_gcm, factor=1, write=True, conserva
         if missing:
             raise RuntimeError("set_gcm_tendencies: LES profiles of %d columns are unknown; call get_les_profiles() "
                                "for every LES first (as splib.step_les_models does)" % len(missing))
+        src = lambda m: batch.profiles[id(m)]                # noqa: E731
+        with_file = write and writer is not None
         keys = _BWD_KEYS + (("Rhobf",) if conservative else ())
-        prof = batch.stack_profiles(keys, lambda m: batch.profiles[id(m)])
+        if with_file:
+            keys = keys + tuple(k for k in ("THL", "presf", "Rhof", "Rhobf", "QR") if k not in keys)
+        prof = batch.stack_profiles(keys, src, upto=None if (with_file or conservative) else "A")
         batch.bwd = backward_batched(batch, prof, dt_gcm, factor, conservative)
         batch.bwd_key = key
-        if write and writer is not None:
-            extra = batch.stack_profiles(("THL", "presf", "Rhof", "Rhobf", "QR"), lambda m: batch.profiles[id(m)])
-            _write_backward(batch, dict(prof, **extra))      # once per launch, for all columns
+        if with_file:
+            _write_backward(batch, prof)         # once per launch, for all columns
+    batch.bwd_raw = (dt_gcm, factor, conservative, batch.profile_generation)
+    return batch.bwd
+
+
+def _backward_rows(batch):
     b = batch.bwd
-    i = batch.index_of(les)
-    for var in ("U", "V", "T", "SH", "QL", "QI", "A"):                           # spcpl.py:535-542
-        gcm.set_profile_tendency(var, les.grid_index, _wrap("f_" + var, b["f_" + var][i].copy()))
+    rows = [_rows_of(b["f_" + v]) for v in _TEND_VARS]
+    if _unit_wrapper is not None:
+        rows = [[_unit_wrapper("f_" + v, x) for x in r] for v, r in zip(_TEND_VARS, rows)]
+    batch.bwd_rows = rows
+    return rows
+
+
+def set_gcm_tendencies(gcm, les, profile, dt_gcm, factor=1, write=True, conservative=False):
+    """splib/spcpl.py:388-555. First call of a step: ONE launch for all columns; every call: the seven
+    ``gcm.set_profile_tendency`` setters for column ``les`` (spcpl.py:535-542)."""
+    try:
+        batch, i = les._spc_batch, les._spc_row
+    except AttributeError:
+        batch = _batch_of(les)
+        i = batch.index_of(les)
+    raw = batch.bwd_raw
+    if (raw is None or raw[0] is not dt_gcm or raw[1] is not factor or raw[2] is not conservative
+            or raw[3] != batch.profile_generation):
+        _ensure_backward(batch, les, profile, dt_gcm, factor, write, conservative)
+    rows = batch.bwd_rows or _backward_rows(batch)
+    setter, gi = gcm.set_profile_tendency, les.grid_index
+    setter("U", gi, rows[0][i])                                               # spcpl.py:535-542
+    setter("V", gi, rows[1][i])
+    setter("T", gi, rows[2][i])
+    setter("SH", gi, rows[3][i])
+    setter("QL", gi, rows[4][i])
+    setter("QI", gi, rows[5][i])
+    setter("A", gi, rows[6][i])
 
 
 def _write_backward(batch, prof):
@@ -840,6 +1011,37 @@ def variability_nudge(les, DT, constantT=False, write=True):
     return variability_nudge_batched([les], DT, constantT, write)[0]
 
 
+def _vnudge_launch(F, Rs, constantT):
+    """stacked host arrays -> ONE launch (K6) -> host results; ``F``: dict of [n x ...] arrays"""
+    eng = get_engine()
+    dev, dt = eng.device, eng.dtype
+    up = lambda a: torch.from_numpy(numpy.ascontiguousarray(a)).to(dev, dt)      # noqa: E731
+    T = {k: up(v) for k, v in F.items() if v is not None}
+    res = eng.variability_nudge(T["qt"], T["qsat"], up(Rs), T["ql_av"], T["qt_av"], T["ql_ref"], presf=T["presf"],
+                                thl=T.get("thl"), ql=T.get("ql"), constantT=constantT)
+    host = {k: v.cpu().numpy() for k, v in res.items()}
+    return host, T["qt"].cpu().numpy(), (T["thl"].cpu().numpy() if constantT else None)
+
+
+def _vnudge_finish(host, rows, dtv, write):
+    """alpha = log(beta) / DT (spcpl.py:739), the spifs rows (spcpl.py:742-744) and scipy's exceptions"""
+    out = []
+    for i in range(host["beta"].shape[0]):
+        beta = host["beta"][i]
+        out.append(dict(beta=beta, alpha=numpy.log(beta) / dtv, qt_std=host["qt_std"][i], a=host["a"][i], status=host["status"][i]))
+    if write and writer is not None:                                          # spcpl.py:742-744
+        writer.write(rows=rows, qt_alpha=numpy.stack([o["alpha"] for o in out]),
+                     qt_beta=numpy.stack([o["beta"] for o in out]), qt_std=numpy.stack([o["qt_std"] for o in out]))
+    st = host["status"]
+    if (st & VN_ERR_SIGN).any():
+        i, k = numpy.argwhere((st & VN_ERR_SIGN) != 0)[0]
+        raise ValueError("f(a) and f(b) must have different signs (variability nudge, LES %d level %d)" % (i, k))
+    if (st & VN_ERR_CONV).any():
+        i, k = numpy.argwhere((st & VN_ERR_CONV) != 0)[0]
+        raise RuntimeError("Failed to converge after 100 iterations. (variability nudge, LES %d level %d)" % (i, k))
+    return out
+
+
 def variability_nudge_batched(les_models, DT, constantT=False, write=True):
     """spcpl.variability_nudge (splib/spcpl.py:613-744) for every LES in ONE launch.  Per LES, as the reference:
     a zero-mean Gaussian field R from numpy's GLOBAL generator (spcpl.py:620-621, drawn in les order), the 3-D
@@ -851,8 +1053,6 @@ def variability_nudge_batched(les_models, DT, constantT=False, write=True):
     les_models = list(les_models)
     if not les_models:
         return []
-    eng = get_engine()
-    dev, dt = eng.device, eng.dtype
     dtv = float(_num(DT))
     Rs, F = [], {k: [] for k in ("qsat", "qt", "ql_av", "qt_av", "presf", "ql_ref", "thl", "ql")}
     for les in les_models:
@@ -873,14 +1073,7 @@ def variability_nudge_batched(les_models, DT, constantT=False, write=True):
     if len(shapes) != 1:
         raise ValueError("variability_nudge_batched: one launch handles LES instances of ONE field shape, got %s; "
                          "call it per group of equal shapes" % sorted(shapes))
-    up = lambda rows: torch.from_numpy(numpy.ascontiguousarray(numpy.stack(rows))).to(dev, dt)      # noqa: E731
-    T = {k: up(v) for k, v in F.items() if v}
-    res = eng.variability_nudge(T["qt"], T["qsat"], up(Rs), T["ql_av"], T["qt_av"], T["ql_ref"], presf=T["presf"],
-                                thl=T.get("thl"), ql=T.get("ql"), constantT=constantT)
-    host = {k: v.cpu().numpy() for k, v in res.items()}
-    qt_new = T["qt"].cpu().numpy()
-    thl_new = T["thl"].cpu().numpy() if constantT else None
-    out = []
+    host, qt_new, thl_new = _vnudge_launch({k: (numpy.stack(v) if v else None) for k, v in F.items()}, numpy.stack(Rs), constantT)
     for i, les in enumerate(les_models):
         target = les.fields if hasattr(les, "fields") else None
         if target is not None:
@@ -891,21 +1084,34 @@ def variability_nudge_batched(les_models, DT, constantT=False, write=True):
             les.set_field("QT", _wrap("qt", qt_new[i]))
             if constantT:
                 les.set_field("THL", _wrap("thl", thl_new[i]))
-        beta = host["beta"][i]
-        alpha = numpy.log(beta) / dtv                                         # spcpl.py:739
-        out.append(dict(beta=beta, alpha=alpha, qt_std=host["qt_std"][i], a=host["a"][i], status=host["status"][i]))
-    if write and writer is not None:                                          # spcpl.py:742-744
-        rows = [_batch_of(les).index_of(les) for les in les_models]
-        writer.write(rows=rows, qt_alpha=numpy.stack([o["alpha"] for o in out]),
-                     qt_beta=numpy.stack([o["beta"] for o in out]), qt_std=numpy.stack([o["qt_std"] for o in out]))
-    st = host["status"]
-    if (st & VN_ERR_SIGN).any():
-        i, k = numpy.argwhere((st & VN_ERR_SIGN) != 0)[0]
-        raise ValueError("f(a) and f(b) must have different signs (variability nudge, LES %d level %d)" % (i, k))
-    if (st & VN_ERR_CONV).any():
-        i, k = numpy.argwhere((st & VN_ERR_CONV) != 0)[0]
-        raise RuntimeError("Failed to converge after 100 iterations. (variability nudge, LES %d level %d)" % (i, k))
-    return out
+    rows = [_batch_of(les).index_of(les) for les in les_models] if (write and writer is not None) else None
+    return _vnudge_finish(host, rows, dtv, write)
+
+
+def variability_nudge_ensemble(ens, DT, constantT=False, write=True):
+    """The same for an LES ENSEMBLE (batched model protocol, sp_coupler_amd.models): the 3-D fields of all columns come
+    from ``ens.get_fields_batched(name) -> [n x itot x jtot x ktot]`` ("Qsat", "QT"; "THL", "QL" with constantT) and go
+    back through ``ens.set_fields_batched(name, array)``; slab means from ``get_profiles_batched``; ``ens.ql_ref`` is
+    what set_les_forcings_batched stored (spcpl.py:348).  R is drawn per column in column order like the per-LES loop."""
+    dtv = float(_num(DT))
+    n = len(ens)
+    qt = _num(ens.get_fields_batched("QT"))
+    _, itot, jtot, ktot = qt.shape
+    Rs = numpy.empty((n, itot, jtot))
+    for i in range(n):
+        R = numpy.random.normal(size=(itot, jtot))                            # spcpl.py:620
+        R -= R.sum() / (itot * jtot)                                          # spcpl.py:621
+        Rs[i] = R
+    av = {k: numpy.empty((n, ktot)) for k in ("QL", "QT", "presf")}
+    ens.get_profiles_batched(("QL", "QT", "presf"), av)
+    F = dict(qsat=_num(ens.get_fields_batched("Qsat")), qt=qt, ql_av=av["QL"], qt_av=av["QT"], presf=av["presf"],
+             ql_ref=_num(ens.ql_ref), thl=_num(ens.get_fields_batched("THL")) if constantT else None,
+             ql=_num(ens.get_fields_batched("QL")) if constantT else None)
+    host, qt_new, thl_new = _vnudge_launch(F, Rs, constantT)
+    ens.set_fields_batched("QT", _wrap("qt", qt_new))                         # spcpl.py:735
+    if constantT:
+        ens.set_fields_batched("THL", _wrap("thl", thl_new))                  # spcpl.py:736-737
+    return _vnudge_finish(host, list(range(n)), dtv, write)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -1,0 +1,102 @@
+"""Transfer plumbing of the drop-in path: groups of named arrays that cross PCIe together (``Arena``: ONE pinned host
+buffer mirrored by ONE device buffer; ``ShardedArena``: the same host buffer mirrored row-block-wise on several GPUs,
+sp_coupler_amd.multi) and the optional per-step HIP-event trace of every copy and launch (``StepTrace``).
+PyTorch is plumbing here: pinned memory, device memory, streams, events."""
+import numpy
+import torch
+
+
+class Arena:
+    """Named arrays packed into ONE pinned host buffer and ONE device buffer, so that a whole group of inputs
+    (or results) crosses PCIe in a single copy.  ``h[name]`` / ``hn[name]`` are the host views (torch / NumPy),
+    ``d[name]`` the device views; every array starts 256-B aligned (the 16-B accesses of the compile-time-geometry
+    kernels need aligned bases).  With a CPU "device" (the test-only oracle engine) host and device are one buffer."""
+
+    ALIGN = 256
+
+    def __init__(self, device, specs):
+        self.device = torch.device(device)
+        off, lay = 0, []
+        for name, shape, dtype in specs:
+            nbytes = int(numpy.prod(shape, dtype=numpy.int64)) * torch.empty((), dtype=dtype).element_size()
+            lay.append((name, tuple(shape), dtype, off, nbytes))
+            off += -(-nbytes // self.ALIGN) * self.ALIGN
+        self.nbytes = off
+        on_gpu = self.device.type == "cuda"
+        self.host = torch.empty(max(off, 1), dtype=torch.uint8, pin_memory=on_gpu)
+        self.dev = torch.empty(max(off, 1), dtype=torch.uint8, device=self.device) if on_gpu else self.host
+        self.h, self.d, self.hn, self.begin, self.end = {}, {}, {}, {}, {}
+        for name, shape, dtype, o, nb in lay:
+            self.h[name] = self.host[o:o + nb].view(dtype).view(shape)
+            self.d[name] = self.dev[o:o + nb].view(dtype).view(shape)
+            self.hn[name] = self.h[name].numpy()
+            self.begin[name], self.end[name] = o, o + nb
+        self.done = None        # event of the last download (created on first use)
+
+    def upload(self, upto=None, what="h2d"):
+        """host -> device (one async copy on the current stream; later kernels on that stream are ordered after it)"""
+        if self.dev is not self.host:
+            n = self.nbytes if upto is None else self.end[upto]
+            if trace is not None:
+                with trace.region(what, n, self.device):
+                    self.dev[:n].copy_(self.host[:n], non_blocking=True)
+            else:
+                self.dev[:n].copy_(self.host[:n], non_blocking=True)
+
+    def download(self, upto=None, what="d2h", start=None):
+        """device -> host of the arrays from ``start`` (default the first) up to and including ``upto`` (default the
+        last), then wait for THAT copy (an event of this arena, not a synchronisation of the whole stream)"""
+        if self.dev is not self.host:
+            n = self.nbytes if upto is None else self.end[upto]
+            o = 0 if start is None else self.begin[start]
+            if trace is not None:
+                with trace.region(what, n - o, self.device):
+                    self.host[o:n].copy_(self.dev[o:n], non_blocking=True)
+            else:
+                self.host[o:n].copy_(self.dev[o:n], non_blocking=True)
+            if self.done is None:
+                self.done = torch.cuda.Event()
+            self.done.record(torch.cuda.current_stream(self.device))
+            self.done.synchronize()
+
+
+class StepTrace:
+    """Optional per-step breakdown of the drop-in path (bench.py `dropin`, tools/dropin_breakdown.py): every PCIe copy
+    and kernel launch of spcpl is bracketed by HIP events on the stream it is issued on.  Install with
+    ``transfer.trace = StepTrace()``; ``summary()`` synchronises and returns name -> {calls, ms, bytes, GBs}."""
+
+    def __init__(self):
+        self.items = []
+
+    class _Region:
+        __slots__ = ("tr", "name", "nbytes", "device", "e0")
+
+        def __init__(self, tr, name, nbytes, device):
+            self.tr, self.name, self.nbytes, self.device = tr, name, nbytes, device
+
+        def __enter__(self):
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream(self.device))
+
+        def __exit__(self, *exc):
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(torch.cuda.current_stream(self.device))
+            self.tr.items.append((self.name, self.nbytes, self.e0, e1))
+
+    def region(self, name, nbytes, device):
+        return StepTrace._Region(self, name, nbytes, device)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, nbytes, e0, e1 in self.items:
+            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "bytes": 0})
+            d["calls"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["bytes"] += nbytes
+        for d in out.values():
+            d["GBs"] = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 and d["bytes"] else None
+        return out
+
+
+trace = None       # a StepTrace while a breakdown is being taken, else None (no events, no overhead)

@@ -25,8 +25,48 @@ def _t(d, out=None):
     return res
 
 
+def _into(res, out):
+    if out:
+        for k, t in out.items():
+            if k in res:
+                t.copy_(res[k].to(t.dtype))
+                res[k] = t
+    return res
+
+
+class _OraclePlan:
+    """plan object with the interface of sp_coupler_amd.engine._Plan (set_scalars / launch / outputs): the product's
+    host logic drives the test engine exactly like the HIP one"""
+
+    class _Args:
+        factor = dt = 0.0
+
+    def __init__(self, run, factor=0.0, dt=1.0):
+        self._run, self.args, self.outputs = run, _OraclePlan._Args(), {}
+        self.args.factor, self.args.dt = factor, dt
+
+    def set_scalars(self, factor, dt):
+        self.args.factor, self.args.dt = float(factor), float(dt)
+
+    def launch(self, stream=None):
+        self.outputs = self._run(self.args.factor, self.args.dt)
+        return self.outputs
+
+
 class OracleEngine:
     device, dtype = torch.device("cpu"), torch.float64
+
+    def plan_forward(self, g, zf, p, factor, dt, zh=None, **kw):
+        return _OraclePlan(lambda f, d: self.forward(g, zf, p, f, d, zh=zh, **kw), factor, dt)
+
+    def plan_backward(self, g, zf, p, factor, dt, **kw):
+        return _OraclePlan(lambda f, d: self.backward(g, zf, p, f, d, **kw), factor, dt)
+
+    def plan_diagnostics(self, g, zf=None, prof=None, out=None, **kw):
+        return _OraclePlan(lambda f, d: _into(self.diagnostics(g, zf, prof), out))
+
+    def plan_cloud_indices(self, zh, Zh, out=None, **kw):
+        return _OraclePlan(lambda f, d: _into({"idx": self.cloud_indices(zh, Zh)}, {"idx": out} if out is not None else None))
 
     def forward(self, g, zf, p, factor, dt, zh=None, want_profiles=False, want_heights=True, couple_surface=False, out=None, **kw):
         pn = _np(p)
@@ -88,6 +128,24 @@ class OracleEngine:
         if les["pf"]:
             res.update({k: numpy.stack(v) for k, v in les.items()})
         return _t(res)
+
+    def variability_nudge(self, qt, qsat, R, ql_av, qt_av, ql_ref, presf=None, thl=None, ql=None, constantT=False, **kw):
+        """oracle/vnudge_oracle.py per column; qt (and thl) updated in place like the HIP engine does"""
+        from oracle import vnudge_oracle as vo
+        n, _, _, k = qt.shape
+        res = {name: numpy.empty((n, k)) for name in ("beta", "a", "qt_std")}
+        res["status"] = numpy.empty((n, k), dtype=numpy.int32)
+        for i in range(n):
+            r = vo.variability_nudge(qt[i].numpy(), qsat[i].numpy(), ql_av[i].numpy(), qt_av[i].numpy(), presf[i].numpy(),
+                                     ql_ref[i].numpy(), R[i].numpy(), 1.0, constantT,
+                                     thl=None if thl is None else thl[i].numpy(), ql=None if ql is None else ql[i].numpy())
+            assert r["error"] is None, r["error"]
+            qt[i].copy_(torch.from_numpy(r["qt"]))
+            if constantT:
+                thl[i].copy_(torch.from_numpy(r["thl"]))
+            for name in ("beta", "a", "qt_std", "status"):
+                res[name][i] = r[name]
+        return {name: torch.from_numpy(v) for name, v in res.items()}
 
     def surface_fluxes(self, Ph_s, T_s, QLflux, QIflux, SHflux, TSflux, **kw):
         rho = Ph_s.numpy() / (orc.rd * T_s.numpy())

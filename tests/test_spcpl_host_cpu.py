@@ -62,15 +62,27 @@ def test_per_les_calls_need_all_profiles_and_stale_profiles_are_not_reused():
     assert len(reqs) == 3 and all(set(r) == {"U", "V", "THL", "QT", "SP", "QL", "QLp"} for r in reqs)
     b1 = spcpl.current_batch()
     assert b1.fwd is not None and b1.fwd["f_u"].shape == (3, 160)
-    # a second gather makes a new batch; the profiles fetched after the LES step carry over to it
+    # a second gather of the SAME columns refills the batch (per-LES handles stay attached, per-step results are
+    # dropped); the profiles fetched after the LES step carry over to it
     for les in les_models:
         les.evolve_model(900.0)
         spcpl.get_les_profiles(les, True)
+    step1 = b1.step_id
     spcpl.gather_gcm_data(gcm, les_models, False)
     b2 = spcpl.current_batch()
-    assert b2 is not b1 and b2.fwd is None and len(b2.profiles) == 3
+    assert b2 is b1 and b2.step_id == step1 + 1 and b2.fwd is None and b2.bwd is None and len(b2.profiles) == 3
+    assert les_models[1]._spc_batch is b2 and les_models[1]._spc_row == 1
     spcpl.set_les_forcings(les_models[1], gcm, True, False, None, dt_gcm=900.0, factor=1.0, couple_surface=False)
     assert b2.fwd is not None
+    # a different set of columns makes a new batch (and the profiles of the columns it shares carry over)
+    spcpl.gather_gcm_data(gcm, les_models[:2], False)
+    b3 = spcpl.current_batch()
+    assert b3 is not b2 and b3.n == 2 and len(b3.profiles) == 2 and les_models[0]._spc_batch is b3
+    # heights are computed on first read, per step, and behave like the float64 row
+    zf = les_models[0].gcm_Zf
+    assert b3.diag_host is None and zf.shape == (19,) and b3.diag_host is not None
+    assert numpy.array_equal(numpy.asarray(zf), b3.diag_host["Zf"][0]) and float(zf[0]) > float(zf[-1]) and len(les_models[0].gcm_Zh) == 20
+    assert numpy.array_equal(zf - numpy.asarray(zf), numpy.zeros(19))
 
 
 def test_unit_wrapper_and_quantity_inputs():
@@ -85,7 +97,9 @@ def test_unit_wrapper_and_quantity_inputs():
         gcm.get_profile_fields = lambda var, cols: Q(orig(var, cols), "si")
         spcpl.gather_gcm_data(gcm, les_models, False)
         spcpl.set_les_forcings_batched(les_models, gcm, False, True, {}, Q(900.0, "s"), 1.0, False)
-        assert {"f_u", "f_v", "f_thl", "f_qt", "f_ps", "f_ql", "ql_ref", "Zf", "Zh"} <= set(seen)
+        assert {"f_u", "f_v", "f_thl", "f_qt", "f_ps", "f_ql", "ql_ref"} <= set(seen) and "Zf" not in seen
+        assert les_models[0].gcm_Zf.number.shape == (19,) and les_models[1].gcm_Zh.unit == "m"      # on first read
+        assert {"Zf", "Zh"} <= set(seen)
         assert les_models[0].tend["U"].shape == (160,)            # the model saw the bare numbers
     finally:
         spcpl.set_unit_wrapper(None)
@@ -251,3 +265,60 @@ def test_spinup_with_an_ensemble_equals_the_per_les_spinup(tmp_path):
     assert ens.model_time == les_a[0].model_time == 200.0
     for k in out[0]:
         assert numpy.array_equal(out[0][k], out[1][k], equal_nan=True), k
+
+
+def test_variance_forcing_on_the_ensemble_path_equals_the_per_les_path():
+    """Round-2 advisor: Coupler(ensemble, qt_forcing='variance') raised AttributeError on the first step with model time
+    > 0 (ql_ref never handed over, no 3-D field access on the batched protocol).  The ensemble now offers
+    get_fields_batched / set_fields_batched; the nudged 3-D qt (and thl with constant T) of every column must equal what
+    the reference's per-LES loop (spcpl.py:377-382, variability_nudge per les) produces from the same fields and the
+    same global random stream."""
+    from tests.test_vnudge import FieldLES, make_les_fields
+    n, nG, nL = 3, 19, 40
+    gcm_a, les_a = models.make_models(n, nG=nG, nL=nL, seed=21)
+    gcm_b = models.BatchedSyntheticGCM(gcm_a.npoints, nG, 21)
+    ens = models.SyntheticLESEnsemble.from_models(les_a)
+    fs = [make_les_fields(8, 8, nL, seed=60 + i) for i in range(n)]
+    # per-LES side: the reference's face (get_field / get_profile / fields namespace)
+    for les, f in zip(les_a, fs):
+        les.f3, les.fields = f, FieldLES._Fields()
+        les.get_field = lambda name, f=f: {"Qsat": f["qsat"], "QT": f["qt"], "THL": f["thl"], "QL": f["ql"]}[name].copy()
+        les.get_profile = lambda name, f=f: {"QL": f["ql_av"], "QT": f["qt_av"]}[name].copy()
+        les.p["presf"] = f["presf"].copy()
+        les.model_time = 900.0
+    # ensemble side: the same numbers stacked
+    ens.attach_fields({"Qsat": numpy.stack([f["qsat"] for f in fs]), "QT": numpy.stack([f["qt"] for f in fs]),
+                       "THL": numpy.stack([f["thl"] for f in fs]), "QL": numpy.stack([f["ql"] for f in fs])})
+    ens.p["presf"] = numpy.stack([f["presf"] for f in fs])
+    ens.model_time = 900.0
+    slab = {"QL": numpy.stack([f["ql_av"] for f in fs]), "QT": numpy.stack([f["qt_av"] for f in fs])}
+    orig = ens.get_profiles_batched
+
+    def profiles(keys, out):                 # the nudge asks for the slab means of the 3-D fields (les.get_profile)
+        if tuple(keys) == ("QL", "QT", "presf"):
+            numpy.copyto(out["QL"], slab["QL"]); numpy.copyto(out["QT"], slab["QT"]); numpy.copyto(out["presf"], ens.p["presf"])
+        else:
+            orig(keys, out)
+    ens.get_profiles_batched = profiles
+
+    spcpl.gather_gcm_data(gcm_a, les_a, False, write=False)
+    numpy.random.seed(11)
+    spcpl.set_les_forcings_batched(les_a, gcm_a, True, True, {}, dt_gcm=900.0, factor=1.0, couple_surface=False,
+                                   qt_forcing='variance', variability_nudge_constant_T=True)
+    spcpl.gather_gcm_data(gcm_b, ens, False, write=False)
+    numpy.random.seed(11)
+    assert spcpl.set_les_forcings_batched(ens, gcm_b, True, True, None, dt_gcm=900.0, factor=1.0, couple_surface=False,
+                                          qt_forcing='variance', variability_nudge_constant_T=True) == []
+    for i, les in enumerate(les_a):
+        assert numpy.array_equal(numpy.asarray(ens.ql_ref[i]), numpy.asarray(les.ql_ref))
+        assert numpy.array_equal(ens.fields3d["QT"][i], les.fields.QT) and not numpy.array_equal(les.fields.QT, fs[i]["qt"])
+        assert numpy.array_equal(ens.fields3d["THL"][i], les.fields.THL)
+    # an ensemble without 3-D field access is refused up front, not with an AttributeError deep inside
+    ens2 = models.SyntheticLESEnsemble.from_models(les_a)
+    del_fields = type("NoFields", (), {})()
+    for name in ("batched", "grid_indices", "zf_cache", "zh_cache", "get_profiles_batched", "set_forcings_batched", "model_time"):
+        setattr(del_fields, name, getattr(ens2, name))
+    del_fields.__class__.__len__ = lambda self: n
+    spcpl.gather_gcm_data(gcm_b, del_fields, False, write=False)
+    with pytest.raises(NotImplementedError, match="get_fields_batched"):
+        spcpl.set_les_forcings_batched(del_fields, gcm_b, True, True, None, 900.0, 1.0, False, qt_forcing='variance')

@@ -237,8 +237,25 @@ def dropin_rate(eng, n_les=1024, steps=30, warmup=5, per_les_steps=5):
                                "ms_per_step": wall2 / per_les_steps * 1e3,
                                "value_model_time_subtracted": n_les * per_les_steps / (wall2 - models.model_seconds),
                                "ms_per_step_models": models.model_seconds / per_les_steps * 1e3,
-                               "note": "`value`: wall time, model time NOT subtracted; `value_model_time_subtracted`: minus the "
-                                       "time inside the stand-in models' own getters / setters (35 calls per column and step)"}
+                               "note": "`value`: wall time of the reference's loop shape (35 model calls per column and step), model "
+                                       "time NOT subtracted; `value_model_time_subtracted`: minus the time inside the stand-in models' "
+                                       "timed methods (the timing wrappers' own overhead stays on the coupler's side); "
+                                       "`value_null_models`: the same loop on models whose methods cost nothing = the coupler's and "
+                                       "driver's own per-column cost, PCIe and kernels included"}
+    # the coupler's OWN per-column cost: the same loop on models whose methods cost nothing (no subtraction needed)
+    gcm3 = models.NullTendencyGCM(n_les + 4, 91, 3)
+    zf3, zh3 = ens2.zf_cache, ens2.zh_cache
+    cpl3 = Coupler(gcm3, [models.NullLES(i + 1, zf3, zh3, 91) for i in range(n_les)])
+    cpl3.step()
+    cpl3.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(per_les_steps):
+        cpl3.step()
+    torch.cuda.synchronize()
+    wall3 = time.perf_counter() - t0
+    out["per_les_protocol"]["value_null_models"] = n_les * per_les_steps / wall3
+    out["per_les_protocol"]["ms_per_step_null_models"] = wall3 / per_les_steps * 1e3
     spcpl.set_engine(None)
     return out
 

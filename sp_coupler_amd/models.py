@@ -545,6 +545,57 @@ class SyntheticLESEnsemble:
         self.model_time = float(t)
 
 
+class NullLES:
+    """An LES face whose methods cost (almost) nothing -- getters hand out one preallocated array / request, setters
+    drop their argument: what a step through it costs is the COUPLER's and the driver's own per-column work (bench.py
+    `dropin.per_les_protocol.value_null_models`; subtracting measured model time instead leaks the timing wrappers'
+    own overhead, ~35 calls per column and step, into the coupler's share)."""
+
+    def __init__(self, grid_index, zf, zh, nG):
+        nL = zf.shape[-1]
+        self.grid_index, self.zf_cache, self.zh_cache = int(grid_index), zf, zh
+        self.lat = self.lon = 0.0
+        self._a, self._s = numpy.zeros(nL), 1.0e5
+        self._ra, self._rs, self._rn = ImmediateRequest(self._a), ImmediateRequest(self._s), ImmediateRequest(None)
+        self._c = numpy.zeros(nG)
+        self._rc = ImmediateRequest(self._c)
+
+    def get_zf(self):
+        return self.zf_cache
+
+    def get_zh(self):
+        return self.zh_cache
+
+    def get_model_time(self):
+        return 0.0
+
+    def evolve_model(self, t, exactEnd=True):
+        return self._rn
+
+    def get_cloudfraction(self, indices, return_request=False):
+        return self._rc if return_request else self._c
+
+
+for _m in ("get_profile_U", "get_profile_V", "get_profile_THL", "get_profile_QT", "get_profile_QL", "get_profile_QL_ice",
+           "get_profile_QR", "get_profile_T", "get_presf", "get_rhof", "get_rhobf"):
+    setattr(NullLES, _m, lambda self, return_request=False: self._ra if return_request else self._a)
+for _m in ("get_surface_pressure", "get_rain"):
+    setattr(NullLES, _m, lambda self, return_request=False: self._rs if return_request else self._s)
+for _m in ("set_tendency_U", "set_tendency_V", "set_tendency_THL", "set_tendency_QT", "set_tendency_QL",
+           "set_tendency_surface_pressure", "set_ref_profile_QL", "set_z0m_surf", "set_z0h_surf", "set_wt_surf", "set_wq_surf"):
+    setattr(NullLES, _m, lambda self, v, return_request=False: self._rn if return_request else None)
+
+
+class NullTendencyGCM(SyntheticGCM):
+    """SyntheticGCM whose per-column tendency setter and second half step cost nothing (pairs with NullLES)"""
+
+    def set_profile_tendency(self, var, grid_index, values):
+        pass
+
+    def evolve_model_from_cloud_scheme(self):
+        self.model_time += self.dt
+
+
 def make_batched_models(n_les, npoints=None, nG=91, nL=160, seed=1):
     """(BatchedSyntheticGCM, SyntheticLESEnsemble) with LES in grid columns 1..n_les -- the fast construction for
     large column counts (one vectorised generator call instead of n_les)."""

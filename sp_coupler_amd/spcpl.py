@@ -354,21 +354,25 @@ class ColumnBatch:
         hn = self.buf.les_in.hn
         rows = [source(les) for les in self.les_models]
         for k in keys:
-            vals = [r[k] for r in rows]
-            v0 = vals[0]
-            if hasattr(v0, "result") and callable(v0.result):
-                vals = [v.result() for v in vals]
-                v0 = vals[0]
-            if hasattr(v0, "number"):
-                vals = [v.number for v in vals]
             dst = hn[k]
-            if dst.ndim == 2:
-                try:
+            try:                                    # fast: all columns hold the same kind of value
+                vals = [r[k] for r in rows]
+                v0 = vals[0]
+                if hasattr(v0, "result") and callable(v0.result):
+                    vals = [v.result() for v in vals]
+                    v0 = vals[0]
+                if hasattr(v0, "number"):
+                    vals = [v.number for v in vals]
+                if dst.ndim == 2:
                     numpy.concatenate(vals, out=dst.reshape(-1))      # n rows of nL float64 -> the [n x nL] block
-                except (TypeError, ValueError):                       # mixed dtypes / shapes: the careful way
-                    numpy.stack([numpy.asarray(v, dtype=numpy.float64) for v in vals], out=dst)
-            else:
-                dst[:] = vals
+                else:
+                    dst[:] = vals
+            except (TypeError, ValueError, AttributeError):           # mixed kinds / dtypes / shapes: column by column
+                vals = [_num(_result(r[k])) for r in rows]
+                if dst.ndim == 2:
+                    numpy.stack(vals, out=dst)
+                else:
+                    dst[:] = vals
         self.buf.les_in.upload(upto=upto, what="h2d_les")
         return {k: self.buf.les_in.d[k] for k in keys}
 

@@ -72,3 +72,44 @@ class RefCoupler:
                 self.log.append(("gcm", les.grid_index, key, numpy.array(b[key])))
         gcm.evolve_model_from_cloud_scheme()
         self.firststep = False
+
+
+def check_reference_loop_shape(n_les=5, nG=19, nL=160, nsteps=2, tol=1e-11):
+    """The reference's own loop shape through the drop-in API -- per-les calls with `profile=profiles[les]`, the
+    profiles resolved to VALUES by the caller while the registry of the product still holds the REQUESTS of the other
+    columns (splib.py:317-332, 586-590) -- against RefCoupler on twin models.  Used on the GPU (tests/test_spcpl_gpu.py)
+    and, with the oracle-backed test engine, on the CPU (tests/test_spcpl_host_cpu.py)."""
+    from sp_coupler_amd import models, spcpl
+    gcm, les_models = models.make_models(n_les, nG=nG, nL=nL, seed=4)
+    gcm_r, les_r = models.make_models(n_les, nG=nG, nL=nL, seed=4)
+    ref = RefCoupler(gcm_r, les_r)
+    profiles, firststep = {}, True
+    for step in range(nsteps):
+        t, dt = gcm.get_model_time(), gcm.get_timestep()
+        gcm.evolve_model_until_cloud_scheme()
+        gcm.evolve_model_cloud_scheme()
+        spcpl.gather_gcm_data(gcm, les_models, False, None, write=False)
+        for les in les_models:
+            profile = {} if firststep else profiles[les]
+            req = spcpl.set_les_forcings(les, gcm, True, firststep, profile, dt_gcm=dt, factor=1.0, couple_surface=False)
+            assert set(req) == {"U", "V", "THL", "QT", "SP", "QL", "QLp"}
+        new = {}
+        for les in les_models:
+            les.evolve_model(t + dt, exactEnd=True)
+            p = spcpl.get_les_profiles(les, True)
+            assert list(p) == spcpl.les_profile_keys
+            new[les] = {k: r.result() for k, r in p.items()}
+        profiles = new
+        for les in les_models:
+            spcpl.set_gcm_tendencies(gcm, les, profile=profiles[les], dt_gcm=dt, factor=1)
+        gcm.evolve_model_from_cloud_scheme()
+        firststep = False
+        ref.step()
+    for var in ("U", "V", "T", "SH", "QL", "QI", "A"):
+        assert numpy.abs(gcm.state[var] - gcm_r.state[var]).max() <= tol * max(numpy.abs(gcm_r.state[var]).max(), 1e-30), var
+    # convert_profiles / get_cloud_fraction per les (init path, splib.py:202-204)
+    u, v, thl, qt, ps, ql = spcpl.convert_profiles(les_models[2], write=False)
+    assert u.shape == (nL,) and ps == gcm.state["Phalf"][les_models[2].grid_index, -1]
+    assert les_models[2].gcm_Zf.shape == (nG,) and les_models[2].gcm_Zh.shape == (nG + 1,)
+    A = spcpl.get_cloud_fraction(les_models[2])
+    assert A.shape == (nG,)

@@ -93,38 +93,8 @@ def test_closed_loop_matches_reference_sequencing(cplsurf):
 
 def test_per_les_api_drop_in_with_unchanged_reference_loop():
     """The reference's own loop shape: per-les calls with `profile=profiles[les]` (splib.py:317-332)."""
-    from sp_coupler_amd import spcpl
-    gcm, les_models = models.make_models(5, nG=19, nL=160, seed=4)
-    gcm_r, les_r = models.make_models(5, nG=19, nL=160, seed=4)
-    ref = RefCoupler(gcm_r, les_r)
-    profiles, firststep = {}, True
-    for step in range(2):
-        t, dt = gcm.get_model_time(), gcm.get_timestep()
-        gcm.evolve_model_until_cloud_scheme(); gcm.evolve_model_cloud_scheme()
-        spcpl.gather_gcm_data(gcm, les_models, False, None, write=False)
-        for les in les_models:
-            profile = {} if firststep else profiles[les]
-            req = spcpl.set_les_forcings(les, gcm, True, firststep, profile, dt_gcm=dt, factor=1.0, couple_surface=False)
-            assert set(req) == {"U", "V", "THL", "QT", "SP", "QL", "QLp"}
-        new = {}
-        for les in les_models:
-            les.evolve_model(t + dt, exactEnd=True)
-            p = spcpl.get_les_profiles(les, True)
-            assert list(p) == spcpl.les_profile_keys
-            new[les] = {k: r.result() for k, r in p.items()}
-        profiles = new
-        for les in les_models:
-            spcpl.set_gcm_tendencies(gcm, les, profile=profiles[les], dt_gcm=dt, factor=1)
-        gcm.evolve_model_from_cloud_scheme()
-        firststep = False
-        ref.step()
-    for var in ("U", "V", "T", "SH", "QL", "QI", "A"):
-        assert numpy.abs(gcm.state[var] - gcm_r.state[var]).max() <= 1e-11 * max(numpy.abs(gcm_r.state[var]).max(), 1e-30)
-    # convert_profiles / get_cloud_fraction per les (init path, splib.py:202-204)
-    u, v, thl, qt, ps, ql = spcpl.convert_profiles(les_models[2], write=False)
-    assert u.shape == (160,) and ps == gcm.state["Phalf"][les_models[2].grid_index, -1]
-    A = spcpl.get_cloud_fraction(les_models[2])
-    assert A.shape == (19,)
+    from tests.ref_driver import check_reference_loop_shape
+    check_reference_loop_shape()
 
 
 def test_gather_quirk_and_output_columns():

@@ -49,6 +49,11 @@ def test_driver_sequencing_bit_identical_to_reference_loop(cplsurf, conservative
     assert not cpl.firststep and len(cpl.timing_rows) == nsteps
 
 
+def test_reference_loop_shape_with_resolved_profiles_next_to_pending_requests():
+    from tests.ref_driver import check_reference_loop_shape
+    check_reference_loop_shape(tol=0.0)          # the test engine shares the oracle's arithmetic: bit-identical
+
+
 def test_per_les_calls_need_all_profiles_and_stale_profiles_are_not_reused():
     gcm, les_models = models.make_models(3, nG=19, nL=160, seed=6)
     spcpl.gather_gcm_data(gcm, les_models, False)

@@ -173,6 +173,16 @@ class Engine:
     def empty(self, *shape, dtype=None):
         return torch.empty(*shape, device=self.device, dtype=dtype or self.dtype)
 
+    # -- transfer plumbing shared with multi.MultiDeviceEngine (which shards the same things over several devices) ----
+    def arena(self, specs, rows=None):
+        """named arrays in ONE pinned host buffer mirrored by ONE device buffer (transfer.Arena)"""
+        from .transfer import Arena
+        return Arena(self.device, specs)
+
+    def to_devices(self, host_array, rows=None):
+        import numpy
+        return torch.from_numpy(numpy.ascontiguousarray(host_array)).to(self.device, self.dtype)
+
     # -- K1 (+K2) ---------------------------------------------------------------------------
     def plan_forward(self, gcm, zf, prof, factor, dt, zh=None, *, want_profiles=False, want_heights=True,
                      want_idx=None, couple_surface=False, cols_per_block=0, out=None):

@@ -1,0 +1,183 @@
+"""All GPUs of the node from ONE process: the column batch split into contiguous row blocks, one per device.
+
+The reference's master is a single process that holds every LES object (``splib/splib.py:146-154``) and loops over
+the columns (``splib.py:317-332``).  ``MultiDeviceEngine`` keeps that shape: it owns one ``Engine`` per visible GPU,
+gives device d rows ``shard_bounds(n, k)[d:d+2]`` of every ``[n x n_lev]`` array (the same partition
+``sharding.py`` uses for one-rank-per-GPU runs; the shared LES grid is replicated), and issues each device's copies
+and launches on that device's own stream, one device after the other -- everything is asynchronous, so the devices
+work concurrently.  Columns are independent (``splib.py:317,330``): no collective, no peer traffic on the hot path.
+``spcpl.get_engine()`` returns one when more than one GPU is visible, so ``driver.Coupler.step`` and the
+reference-named ``spcpl`` calls use every GPU without any change on the caller's side.
+
+Plans mirror ``engine._Plan`` (``set_scalars`` / ``launch`` / ``outputs``): a ``MultiPlan`` holds the per-device
+plans, its ``outputs`` are ``transfer.Sharded`` arrays.  Small batches stay on fewer devices (``MIN_COLS_PER_DEVICE``):
+a launch of a few hundred columns is latency-bound and gains nothing from being split.
+"""
+import os
+
+import torch
+
+from .sharding import shard_bounds
+from .transfer import Sharded, ShardedArena
+
+MIN_COLS_PER_DEVICE = 2048
+
+
+class MultiPlan:
+    def __init__(self, plans, outputs):
+        self.plans, self.outputs = plans, outputs
+
+    def set_scalars(self, factor, dt):
+        for p in self.plans:
+            if p is not None:
+                p.set_scalars(factor, dt)
+
+    def launch(self, stream=None):
+        if stream is not None:
+            raise ValueError("a multi-device plan launches on each device's current stream")
+        for p in self.plans:
+            if p is not None:
+                p.launch()
+        return self.outputs
+
+    def describe(self):
+        return [p.describe() if p is not None else None for p in self.plans]
+
+
+def _part(x, d):
+    """device d's share of an argument: a Sharded's part, or the object itself (scalars, None)"""
+    return x.parts[d] if isinstance(x, Sharded) else x
+
+
+def _parts_of(dct, d):
+    return None if dct is None else {k: _part(v, d) for k, v in dct.items()}
+
+
+class MultiDeviceEngine:
+    """``engines``: one ``Engine`` per device (default: every visible GPU, or the ids in ``SPC_DEVICES=0,1,...``).
+    Tests pass other engine objects with the same interface (two test engines on the CPU; two engines on one GPU)."""
+
+    def __init__(self, engines=None, dtype=torch.float64, min_cols_per_device=MIN_COLS_PER_DEVICE):
+        if engines is None:
+            from .engine import Engine
+            ids = [int(x) for x in os.environ["SPC_DEVICES"].split(",")] if os.environ.get("SPC_DEVICES") else \
+                list(range(torch.cuda.device_count()))
+            engines = [Engine("cuda:%d" % i, dtype=dtype) for i in ids]
+        if not engines:
+            raise RuntimeError("MultiDeviceEngine needs at least one engine")
+        self.engines = list(engines)
+        self.primary = self.engines[0]
+        self.device, self.dtype = self.primary.device, self.primary.dtype     # the primary device (slow paths, traces)
+        self.lib = getattr(self.primary, "lib", None)
+        self.min_cols_per_device = int(min_cols_per_device)
+
+    # -- partition ------------------------------------------------------------------------------------------------
+    def devices_for(self, n):
+        """how many devices a batch of n columns is split over (>= min_cols_per_device columns each)"""
+        return max(1, min(len(self.engines), n // max(1, self.min_cols_per_device)))
+
+    def bounds_for(self, n):
+        k = self.devices_for(n)
+        b = shard_bounds(n, k)
+        return b + [n] * (len(self.engines) - k)          # unused devices get empty blocks
+
+    def arena(self, specs, rows):
+        return ShardedArena([e.device for e in self.engines], self.bounds_for(rows), specs, rows)
+
+    def to_devices(self, host_array, rows=None):
+        """a host array on every device: replicated (``rows`` None: the shared LES grid) or row-sharded"""
+        t = torch.from_numpy(host_array)
+        if rows is None:
+            return Sharded([t.to(e.device, e.dtype) for e in self.engines], None)
+        b = self.bounds_for(rows)
+        return Sharded([t[b[i]:b[i + 1]].to(e.device, e.dtype) for i, e in enumerate(self.engines)], b)
+
+    # -- plans: one per device that holds rows ----------------------------------------------------------------------
+    def _plans(self, make, example):
+        """``make(engine, d)`` for every device with a non-empty row block of ``example`` (a Sharded with bounds)"""
+        b = example.bounds
+        return [make(e, d) if b[d + 1] > b[d] else None for d, e in enumerate(self.engines)]
+
+    @staticmethod
+    def _outputs(plans, bounds):
+        keys = next(p for p in plans if p is not None).outputs.keys()
+        ref = {k: next(p for p in plans if p is not None).outputs[k] for k in keys}
+        out = {}
+        for k in keys:
+            parts = [p.outputs[k] if p is not None else ref[k][:0] for p in plans]
+            out[k] = Sharded(parts, bounds)
+        return out
+
+    def plan_forward(self, gcm, zf, prof, factor, dt, zh=None, out=None, **kw):
+        ex = gcm["T"]
+        plans = self._plans(lambda e, d: e.plan_forward(_parts_of(gcm, d), _part(zf, d), _parts_of(prof, d), factor, dt,
+                                                        zh=_part(zh, d), out=_parts_of(out, d), **kw), ex)
+        return MultiPlan(plans, self._outputs(plans, ex.bounds))
+
+    def plan_backward(self, gcm, zf, prof, factor, dt, Zf=None, zh=None, Zh=None, out=None, **kw):
+        ex = gcm["T"]
+        plans = self._plans(lambda e, d: e.plan_backward(_parts_of(gcm, d), _part(zf, d), _parts_of(prof, d), factor, dt,
+                                                         Zf=_part(Zf, d), zh=_part(zh, d), Zh=_part(Zh, d),
+                                                         out=_parts_of(out, d), **kw), ex)
+        return MultiPlan(plans, self._outputs(plans, ex.bounds))
+
+    def plan_diagnostics(self, gcm, zf=None, prof=None, out=None, **kw):
+        ex = gcm["T"]
+        plans = self._plans(lambda e, d: e.plan_diagnostics(_parts_of(gcm, d), _part(zf, d), _parts_of(prof, d),
+                                                            out=_parts_of(out, d), **kw), ex)
+        return MultiPlan(plans, self._outputs(plans, ex.bounds))
+
+    def plan_cloud_indices(self, zh, Zh, out=None, **kw):
+        plans = self._plans(lambda e, d: e.plan_cloud_indices(_part(zh, d), _part(Zh, d), out=_part(out, d), **kw), Zh)
+        return MultiPlan(plans, self._outputs(plans, Zh.bounds))
+
+    def plan_exchange(self, gcm, zf, zh, prof, factor_les, factor_gcm, dt, cols_per_block=0):
+        """the lean K1 / K3 pair of ``Engine.plan_exchange`` on every device's rows"""
+        lean = {k: v for k, v in prof.items() if k not in ("Rain", "rain_last")}
+        fp = self.plan_forward(gcm, zf, lean, factor_les, dt, zh=zh, want_profiles=False, want_heights=False,
+                               cols_per_block=cols_per_block)
+        bp = self.plan_backward(gcm, zf, prof, factor_gcm, dt, Zf=None, want_start_index=False, cols_per_block=cols_per_block)
+        return fp, bp
+
+    # -- convenience / slow paths: the whole batch on the primary device ----------------------------------------------
+    @staticmethod
+    def whole(x, device):
+        if isinstance(x, Sharded):
+            return x.gather(device)
+        if isinstance(x, dict):
+            return {k: MultiDeviceEngine.whole(v, device) for k, v in x.items()}
+        return x
+
+    def forward(self, gcm, zf, prof, factor, dt, **kw):
+        w = lambda x: self.whole(x, self.primary.device)       # noqa: E731
+        if "zh" in kw:
+            kw["zh"] = w(kw["zh"])
+        return self.primary.forward(w(gcm), w(zf), w(prof), factor, dt, **kw)
+
+    def backward(self, gcm, zf, prof, factor, dt, **kw):
+        w = lambda x: self.whole(x, self.primary.device)       # noqa: E731
+        return self.primary.backward(w(gcm), w(zf), w(prof), factor, dt, **{k: w(v) for k, v in kw.items()})
+
+    def diagnostics(self, gcm, zf=None, prof=None, **kw):
+        w = lambda x: self.whole(x, self.primary.device)       # noqa: E731
+        return self.primary.diagnostics(w(gcm), w(zf), w(prof), **kw)
+
+    def cloud_indices(self, zh, Zh, **kw):
+        return self.primary.cloud_indices(self.whole(zh, self.primary.device), self.whole(Zh, self.primary.device), **kw)
+
+    def surface_fluxes(self, *a, **kw):
+        return self.primary.surface_fluxes(*a, **kw)
+
+    def variability_nudge(self, *a, **kw):
+        return self.primary.variability_nudge(*a, **kw)
+
+    def synchronize(self):
+        for e in self.engines:
+            if e.device.type == "cuda":
+                torch.cuda.synchronize(e.device)
+
+
+def describe_partition(engine, n):
+    """text for logs / bench output: which rows go where"""
+    b = engine.bounds_for(n)
+    return ", ".join("%s: rows %d-%d" % (e.device, b[i], b[i + 1]) for i, e in enumerate(engine.engines) if b[i + 1] > b[i])

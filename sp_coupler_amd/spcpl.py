@@ -56,9 +56,20 @@ writer_rows = {}   # GCM grid index -> column index in the writer's file, for th
 
 
 def get_engine():
+    """the engine of this process: every visible GPU behind ONE master process (multi.MultiDeviceEngine: the column
+    batch split into row blocks, one per GPU -- the reference's master is one process holding all LES objects,
+    splib/splib.py:146-154) when there are several; a plain ``Engine`` with one GPU, inside a one-rank-per-GPU job
+    (WORLD_SIZE > 1: that rank's LOCAL_RANK device) or with SPC_SINGLE_GPU=1."""
     global _engine
     if _engine is None:
-        _engine = Engine()
+        import os
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            _engine = Engine("cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")))
+        elif torch.cuda.device_count() > 1 and os.environ.get("SPC_SINGLE_GPU") != "1":
+            from .multi import MultiDeviceEngine
+            _engine = MultiDeviceEngine()
+        else:
+            _engine = Engine()
     return _engine
 
 
@@ -87,6 +98,13 @@ def _num(q):
     return numpy.asarray(q, dtype=numpy.float64)
 
 
+def _to_host(t):
+    """device tensor (or a transfer.Sharded array of a multi-device engine) -> NumPy array"""
+    if isinstance(t, transfer.Sharded):
+        t = t.gather()
+    return t.cpu().numpy()
+
+
 def _result(x):
     """value of an async request (``.result()``) or the value itself"""
     return x.result() if hasattr(x, "result") and callable(x.result) else x
@@ -107,25 +125,25 @@ class StepBuffers:
 
     def __init__(self, engine, n, n_total, nG, nL, with_surf):
         self.engine, self.n, self.n_total, self.nG, self.nL = engine, n, n_total, nG, nL
-        dev, dt = engine.device, engine.dtype
+        dt = engine.dtype
         g = [(v, (n_total, nG + 1 if v in ("Phalf", "Zghalf") else nG), dt) for v in gcm_vars]
         if with_surf:
             g += [(v, (n_total,), dt) for v in surf_vars]
-        self.gcm_in = Arena(dev, g)
+        self.gcm_in = engine.arena(g, rows=n)
         # upload order = order of need: what K1 reads (first step: only these are known), then what only K3 reads, then
         # the diagnostics of conservative coarsening / spifs -- a copy "up to X" never carries more than it must
-        self.les_in = Arena(dev, [(k, (n, nL), dt) for k in _LES_FWD_LEVELS] + [(k, (n,), dt) for k in _LES_IN_SCALARS]
+        self.les_in = engine.arena([(k, (n, nL), dt) for k in _LES_FWD_LEVELS] + [(k, (n,), dt) for k in _LES_IN_SCALARS]
                             + [(k, (n, nL), dt) for k in _LES_BWD_LEVELS] + [("A", (n, nG), dt)]
-                            + [(k, (n, nL), dt) for k in _LES_DIAG_LEVELS])
+                            + [(k, (n, nL), dt) for k in _LES_DIAG_LEVELS], rows=n)
         # what the 7 LES setters + get_cloudfraction need comes first ("core": downloaded every step); heights
         # and surface fluxes follow and cross PCIe only when somebody asks for them
-        self.fwd_out = Arena(dev, [(k, (n, nL), dt) for k in ("f_u", "f_v", "f_thl", "f_qt", "f_ql", "ql_ref")]
+        self.fwd_out = engine.arena([(k, (n, nL), dt) for k in ("f_u", "f_v", "f_thl", "f_qt", "f_ql", "ql_ref")]
                              + [("f_ps", (n,), dt), ("idx", (n, nG), _I32)]
                              + [("wthl", (n,), dt), ("wqt", (n,), dt), ("Zf", (n, nG), dt), ("Zh", (n, nG + 1), dt),
                                 ("Tv", (n, nG), dt), ("THL", (n, nG), dt), ("QT", (n, nG), dt)]
-                             + [(k, (n, nL), dt) for k in ("u", "v", "thl", "qt")] + [("ps", (n,), dt)])
-        self.bwd_out = Arena(dev, [(k, (n, nG), dt) for k in ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A")]
-                             + [("start_index", (n,), _I32)])
+                             + [(k, (n, nL), dt) for k in ("u", "v", "thl", "qt")] + [("ps", (n,), dt)], rows=n)
+        self.bwd_out = engine.arena([(k, (n, nG), dt) for k in ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A")]
+                                    + [("start_index", (n,), _I32)], rows=n)
         self.plans = {}
         self.grid_key = None
         self.zf = self.zh = self.zf_host = self.zh_host = None
@@ -133,10 +151,10 @@ class StepBuffers:
     def set_grid(self, zf_host, zh_host):
         key = (zf_host.shape, zf_host.tobytes(), zh_host.tobytes()) if zf_host.size <= 4096 else None
         if key is None or key != self.grid_key:
-            dev, dt = self.engine.device, self.engine.dtype
             self.zf_host, self.zh_host = zf_host, zh_host
-            self.zf = torch.from_numpy(numpy.ascontiguousarray(zf_host)).to(dev, dt)
-            self.zh = torch.from_numpy(numpy.ascontiguousarray(zh_host)).to(dev, dt)
+            rows = None if zf_host.ndim == 1 else self.n           # shared grid: replicated; per-column grid: row-sharded
+            self.zf = self.engine.to_devices(zf_host, rows)
+            self.zh = self.engine.to_devices(zh_host, rows)
             self.grid_key = key
             self.plans = {}
 
@@ -504,13 +522,13 @@ def forward_batched(batch, profiles, dt_gcm, factor, couple_surface=False):
         batch.gcm, batch.zf, prof, float(factor), dt, zh=batch.zh, want_profiles=False, want_heights=False,
         couple_surface=couple_surface, out=out))
     plan.set_scalars(float(factor), dt)
-    res = _launch(batch, plan, "k1")
+    _launch(batch, plan, "k1")
     b.fwd_out.download(upto="wqt" if couple_surface else "idx", what="d2h_forcings")
     host = {k: b.fwd_out.hn[k] for k in _FWD_CORE}
     if couple_surface:
         host["wthl"], host["wqt"] = b.fwd_out.hn["wthl"], b.fwd_out.hn["wqt"]
-        host["z0m"] = res["z0m"].cpu().numpy() if "z0m" in res else batch.surf_host["Z0M"][:batch.n]
-        host["z0h"] = res["z0h"].cpu().numpy() if "z0h" in res else batch.surf_host["Z0H"][:batch.n]
+        host["z0m"] = numpy.array(batch.surf_host["Z0M"][:batch.n])      # pass-throughs (spcpl.py:146-147): the host has them
+        host["z0h"] = numpy.array(batch.surf_host["Z0H"][:batch.n])
     host["ql"] = host["ql_ref"]
     return host
 
@@ -608,7 +626,7 @@ def convert_profiles(les, write=True):
         z = torch.zeros(batch.n, nL, device=eng.device, dtype=eng.dtype)
         dummy = {"U": z, "V": z, "THL": z, "QT": z, "QL": z, "PS": torch.zeros(batch.n, device=eng.device, dtype=eng.dtype)}
         res = eng.forward(batch.gcm, batch.zf, dummy, 0.0, 1.0, want_profiles=True, want_heights=True)
-        batch.conv = {k: res[k].cpu().numpy() for k in ("u", "v", "thl", "qt", "ps", "ql_ref", "Zf", "Zh")}
+        batch.conv = {k: _to_host(res[k]) for k in ("u", "v", "thl", "qt", "ps", "ql_ref", "Zf", "Zh")}
     c = batch.conv
     les.gcm_Zf = _wrap("Zf", c["Zf"][i])                                     # spcpl.py:200
     les.gcm_Zh = _wrap("Zh", c["Zh"][i])                                     # spcpl.py:201
@@ -923,7 +941,7 @@ def _write_backward(batch, prof):
     the slab means incl. THL, presf, Rhof, Rhobf, QR."""
     b, n = batch.bwd, batch.n
     d = batch.engine.diagnostics(batch.gcm, batch.zf, prof)                                  # K5: t, ql_water
-    h = lambda t: t.cpu().numpy()                # noqa: E731
+    h = _to_host
     writer.write(u=h(prof["U"]), v=h(prof["V"]), presf=h(prof["presf"]), rhof=h(prof["Rhof"]),
                  rhobf=h(prof["Rhobf"]), qt=h(prof["QT"]), ql=h(prof["QL"]), ql_ice=h(prof["QL_ice"]),
                  ql_water=h(d["ql_water"]), thl=h(prof["THL"]), t=h(d["t"]), t_=h(prof["T"]), qr=h(prof["QR"]),
@@ -984,7 +1002,7 @@ def write_les_profiles_batched(les_models):
                          "QL_ice": m.get_profile_QL_ice(), "QR": m.get_profile_QR(), "T": m.get_profile_T()}
         prof = batch.stack_profiles(keys, src)
     d = batch.engine.diagnostics(batch.gcm, batch.zf, prof)                                  # K5: t, ql_water
-    h = lambda t: t.cpu().numpy()                # noqa: E731
+    h = _to_host
     out = dict(u=h(prof["U"]), v=h(prof["V"]), presf=h(prof["presf"]), qt=h(prof["QT"]), ql=h(prof["QL"]),
                ql_ice=h(prof["QL_ice"]), ql_water=h(d["ql_water"]), thl=h(prof["THL"]), t=h(d["t"]), t_=h(prof["T"]),
                qr=h(prof["QR"]))

@@ -100,3 +100,120 @@ class StepTrace:
 
 
 trace = None       # a StepTrace while a breakdown is being taken, else None (no events, no overhead)
+
+
+class Sharded:
+    """One [n x ...] array living as contiguous ROW BLOCKS on several devices (``parts[d]`` holds rows
+    ``bounds[d]:bounds[d+1]`` on device d), or -- ``bounds`` None -- a small array replicated on every device (the
+    shared LES grid).  Only what the coupling path needs: shape, per-device parts, gathering onto one device."""
+
+    def __init__(self, parts, bounds=None):
+        self.parts, self.bounds = list(parts), bounds
+
+    @property
+    def shape(self):
+        p = self.parts[0]
+        return tuple(p.shape) if self.bounds is None else (self.bounds[-1],) + tuple(p.shape[1:])
+
+    def dim(self):
+        return self.parts[0].dim()
+
+    def __getitem__(self, key):
+        """``t[:n]`` with n = all rows (what ColumnBatch asks of the GCM arrays): the sharded rows are the SP rows already"""
+        if isinstance(key, slice) and key.start in (None, 0) and key.step in (None, 1) and (
+                key.stop is None or self.bounds is None or key.stop == self.bounds[-1]):
+            return self
+        raise IndexError("a Sharded array can only be taken whole")
+
+    def gather(self, device=None):
+        """the whole array on ONE device (slow paths: diagnostics for the spifs writer, convert_profiles)"""
+        device = self.parts[0].device if device is None else device
+        if self.bounds is None:
+            return self.parts[0].to(device)
+        return torch.cat([p.to(device) for p in self.parts if p.shape[0]], dim=0)
+
+
+class ShardedArena:
+    """``Arena`` for several devices: the SAME single pinned host buffer with full-length host views (so everything on
+    the host side -- model getters writing into it, setters reading from it -- is unchanged), mirrored on device d by a
+    buffer that holds rows ``bounds[d]:bounds[d+1]`` of every array.  Copies go per (device, array) on that device's
+    current stream -- the devices' DMA engines run concurrently -- and a download waits for one event per device.
+    ``rows``: the number of leading rows that are sharded (arrays may be longer on the host: the extra output columns of
+    the GCM state stay host-only)."""
+
+    ALIGN = Arena.ALIGN
+
+    def __init__(self, devices, bounds, specs, rows):
+        self.devices = [torch.device(d) for d in devices]
+        self.device = self.devices[0]
+        self.bounds, self.rows = list(bounds), rows
+        off, lay = 0, []
+        for name, shape, dtype in specs:
+            nbytes = int(numpy.prod(shape, dtype=numpy.int64)) * torch.empty((), dtype=dtype).element_size()
+            lay.append((name, tuple(shape), dtype, off, nbytes))
+            off += -(-nbytes // self.ALIGN) * self.ALIGN
+        self.nbytes = off
+        on_gpu = self.device.type == "cuda"
+        self.host = torch.empty(max(off, 1), dtype=torch.uint8, pin_memory=on_gpu)
+        self.h, self.d, self.hn, self.begin, self.end, self.order = {}, {}, {}, {}, {}, []
+        parts = {name: [] for name, *_ in lay}
+        for di, dev in enumerate(self.devices):
+            lo, hi = self.bounds[di], self.bounds[di + 1]
+            o_d, lay_d = 0, []
+            for name, shape, dtype, _, _ in lay:
+                if not shape or shape[0] < rows:
+                    raise ValueError("ShardedArena: %s has %s rows, fewer than the %d sharded rows" % (name, shape[:1], rows))
+                shp = (hi - lo,) + shape[1:]
+                nb = int(numpy.prod(shp, dtype=numpy.int64)) * torch.empty((), dtype=dtype).element_size()
+                lay_d.append((name, shp, dtype, o_d, nb))
+                o_d += -(-nb // self.ALIGN) * self.ALIGN
+            buf = torch.empty(max(o_d, 1), dtype=torch.uint8, device=dev)
+            for name, shp, dtype, o, nb in lay_d:
+                parts[name].append(buf[o:o + nb].view(dtype).view(shp))
+        for name, shape, dtype, o, nb in lay:
+            self.h[name] = self.host[o:o + nb].view(dtype).view(shape)
+            self.hn[name] = self.h[name].numpy()
+            self.d[name] = Sharded(parts[name], self.bounds)
+            self.begin[name], self.end[name] = o, o + nb
+            self.order.append(name)
+        self.done = [None] * len(self.devices)
+
+    def _names(self, upto, start):
+        i0 = 0 if start is None else self.order.index(start)
+        i1 = len(self.order) if upto is None else self.order.index(upto) + 1
+        return self.order[i0:i1]
+
+    def upload(self, upto=None, what="h2d", start=None):
+        names = self._names(upto, start)
+        for di, dev in enumerate(self.devices):
+            lo, hi = self.bounds[di], self.bounds[di + 1]
+            if hi == lo:
+                continue
+            with torch.cuda.device(dev) if dev.type == "cuda" else _Nothing():
+                for name in names:
+                    self.d[name].parts[di].copy_(self.h[name][lo:hi], non_blocking=True)
+
+    def download(self, upto=None, what="d2h", start=None):
+        names = self._names(upto, start)
+        for di, dev in enumerate(self.devices):
+            lo, hi = self.bounds[di], self.bounds[di + 1]
+            if hi == lo:
+                continue
+            with torch.cuda.device(dev) if dev.type == "cuda" else _Nothing():
+                for name in names:
+                    self.h[name][lo:hi].copy_(self.d[name].parts[di], non_blocking=True)
+                if dev.type == "cuda":
+                    if self.done[di] is None:
+                        self.done[di] = torch.cuda.Event()
+                    self.done[di].record(torch.cuda.current_stream(dev))
+        for ev in self.done:
+            if ev is not None:
+                ev.synchronize()
+
+
+class _Nothing:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False

@@ -56,11 +56,23 @@ class _OraclePlan:
 class OracleEngine:
     device, dtype = torch.device("cpu"), torch.float64
 
+    def arena(self, specs, rows=None):
+        from sp_coupler_amd.transfer import Arena
+        return Arena(self.device, specs)
+
+    def to_devices(self, host_array, rows=None):
+        return torch.from_numpy(numpy.ascontiguousarray(host_array)).to(self.device, self.dtype)
+
     def plan_forward(self, g, zf, p, factor, dt, zh=None, **kw):
         return _OraclePlan(lambda f, d: self.forward(g, zf, p, f, d, zh=zh, **kw), factor, dt)
 
     def plan_backward(self, g, zf, p, factor, dt, **kw):
         return _OraclePlan(lambda f, d: self.backward(g, zf, p, f, d, **kw), factor, dt)
+
+    def plan_exchange(self, g, zf, zh, p, factor_les, factor_gcm, dt, cols_per_block=0):
+        lean = {k: v for k, v in p.items() if k not in ("Rain", "rain_last")}
+        return (self.plan_forward(g, zf, lean, factor_les, dt, zh=zh, want_profiles=False, want_heights=False),
+                self.plan_backward(g, zf, p, factor_gcm, dt, Zf=None))
 
     def plan_diagnostics(self, g, zf=None, prof=None, out=None, **kw):
         return _OraclePlan(lambda f, d: _into(self.diagnostics(g, zf, prof), out))

@@ -1,0 +1,111 @@
+"""multi.MultiDeviceEngine: every GPU of the node behind the ONE master process the reference has
+(splib/splib.py:146-154) -- the column batch split into contiguous row blocks, one per device, no collective.
+
+CPU: two (three) oracle-backed test engines stand for the devices; the partitioning, the per-(device, array) copies of
+``transfer.ShardedArena`` and the per-device plans must reproduce the single-engine run of the same closed loop bit
+for bit (same arithmetic, different placement).  GPU (-m gpu): two real ``Engine`` objects on the one card of the
+test box, through the HIP kernels, against the single-engine path."""
+import numpy
+import pytest
+
+from sp_coupler_amd import models, spcpl
+from sp_coupler_amd.multi import MultiDeviceEngine, describe_partition
+from sp_coupler_amd.sharding import shard_bounds
+
+
+def _closed_loop(engine, n_les, nsteps, batched, cplsurf=False, conservative=False, nG=19, nL=40):
+    from sp_coupler_amd.driver import Coupler
+    spcpl.set_engine(engine)
+    try:
+        if batched:
+            gcm, les = models.make_batched_models(n_les, nG=nG, nL=nL, seed=5)
+        else:
+            gcm, les = models.make_models(n_les, nG=nG, nL=nL, seed=5)
+        cpl = Coupler(gcm, les, cplsurf=cplsurf, conservative_coarsening=conservative, les_forcing_factor=0.9)
+        cpl.run(nsteps)
+        b = spcpl.current_batch()
+        heights = None if batched else (numpy.asarray(les[-1].gcm_Zf), numpy.asarray(les[-1].gcm_Zh))
+        idx = numpy.array(spcpl._index_map(b))
+        kinds = (type(b.buf.gcm_in).__name__, sorted({type(p).__name__ for p in b.buf.plans.values()}))
+        return {k: v.copy() for k, v in gcm.state.items()}, heights, idx, kinds
+    finally:
+        spcpl.set_engine(None)
+
+
+@pytest.mark.parametrize("ndev,n_les,batched,cplsurf,conservative", [(2, 7, False, False, False), (3, 8, True, True, False),
+                                                                     (2, 5, True, False, True), (3, 2, False, True, False)])
+def test_row_blocks_over_several_engines_equal_one_engine(ndev, n_les, batched, cplsurf, conservative):
+    from tests.fake_engine import OracleEngine
+    ref = _closed_loop(OracleEngine(), n_les, 3, batched, cplsurf, conservative)
+    multi = MultiDeviceEngine([OracleEngine() for _ in range(ndev)], min_cols_per_device=1)
+    assert multi.devices_for(n_les) == min(ndev, n_les)
+    assert multi.bounds_for(n_les)[:min(ndev, n_les) + 1] == shard_bounds(n_les, min(ndev, n_les))
+    got = _closed_loop(multi, n_les, 3, batched, cplsurf, conservative)
+    for var in ref[0]:
+        assert numpy.array_equal(ref[0][var], got[0][var], equal_nan=True), var
+    if ref[1] is not None:
+        assert numpy.array_equal(ref[1][0], got[1][0]) and numpy.array_equal(ref[1][1], got[1][1])
+    assert numpy.array_equal(ref[2], got[2])
+    assert ref[3][0] == "Arena" and got[3] == ("ShardedArena", ["MultiPlan"]), (ref[3], got[3])
+
+
+def test_small_batches_stay_on_one_device_and_the_partition_is_the_sharding_one():
+    from tests.fake_engine import OracleEngine
+    m = MultiDeviceEngine([OracleEngine() for _ in range(8)])
+    assert m.devices_for(1024) == 1 and m.bounds_for(1024) == [0, 1024] + [1024] * 7
+    assert m.devices_for(35718) == 8 and m.bounds_for(35718) == shard_bounds(35718, 8)
+    assert m.devices_for(5000) == 2 and m.bounds_for(5000)[:3] == [0, 2500, 5000]
+    assert "rows 0-2500" in describe_partition(m, 5000)
+
+
+def test_get_engine_inside_a_rank_per_gpu_job_takes_that_ranks_device(monkeypatch):
+    """one-rank-per-GPU jobs (bench.py --gpus N, sharding.ShardedExchange) must not have every rank grab every GPU"""
+    import sp_coupler_amd.spcpl as sp
+    made = []
+    monkeypatch.setattr(sp, "Engine", lambda *a, **k: made.append(a) or object())
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    sp.set_engine(None)
+    try:
+        sp.get_engine()
+        assert made == [("cuda:3",)]
+    finally:
+        sp.set_engine(None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batched,cplsurf", [(True, False), (False, True)])
+def test_two_engines_on_one_gpu_through_the_hip_kernels(batched, cplsurf):
+    from sp_coupler_amd.engine import Engine
+    ref = _closed_loop(Engine("cuda:0"), 700, 2, batched, cplsurf, nG=91, nL=160)
+    multi = MultiDeviceEngine([Engine("cuda:0"), Engine("cuda:0")], min_cols_per_device=100)
+    assert multi.devices_for(700) == 2
+    got = _closed_loop(multi, 700, 2, batched, cplsurf, nG=91, nL=160)
+    for var in ref[0]:
+        assert numpy.array_equal(ref[0][var], got[0][var], equal_nan=True), var
+    assert numpy.array_equal(ref[2], got[2])
+
+
+@pytest.mark.gpu
+def test_multi_device_exchange_plans_equal_the_single_engine_plans_bitwise():
+    """Engine.plan_exchange (what bench.py times) vs MultiDeviceEngine.plan_exchange on the same 5000 columns"""
+    import torch
+    from sp_coupler_amd import synthetic
+    from sp_coupler_amd.engine import Engine
+    eng = Engine("cuda:0")
+    gcm, zf, zh, prof = synthetic.make_batch(5000, 91, 160, seed=77, couple_surface=False)
+    g = {k: torch.from_numpy(v).to(eng.device) for k, v in gcm.items()}
+    p = {k: torch.from_numpy(v).to(eng.device) for k, v in prof.items()}
+    zf_d, zh_d = torch.from_numpy(zf).to(eng.device), torch.from_numpy(zh).to(eng.device)
+    fp, bp = eng.plan_exchange(g, zf_d, zh_d, p, 1.0, 1.0, 900.0)
+    fp.launch(), bp.launch()
+    multi = MultiDeviceEngine([eng, Engine("cuda:0"), Engine("cuda:0")], min_cols_per_device=1000)
+    gs = {k: multi.to_devices(v, rows=5000) for k, v in gcm.items()}
+    ps = {k: multi.to_devices(v, rows=5000) for k, v in prof.items()}
+    mfp, mbp = multi.plan_exchange(gs, multi.to_devices(zf), multi.to_devices(zh), ps, 1.0, 1.0, 900.0)
+    assert [d is not None for d in mfp.describe()] == [True, True, True]
+    mfp.launch(), mbp.launch()
+    multi.synchronize()
+    for plan, mplan in ((fp, mfp), (bp, mbp)):
+        for k, t in plan.outputs.items():
+            assert numpy.array_equal(t.cpu().numpy(), mplan.outputs[k].gather().cpu().numpy(), equal_nan=True), k

@@ -35,24 +35,7 @@ def test_shard_rows_replicates_shared_grid():
     assert s["Z0M"].shape == (4,)
 
 
-class OracleEngine:
-    """TEST-ONLY stand-in for sp_coupler_amd.engine.Engine on a GPU-less box."""
-    device, dtype = torch.device("cpu"), torch.float64
-
-    def forward(self, g, zf, p, factor, dt, zh=None, **kw):
-        from oracle import spcpl_oracle as orc
-        gn = {k: v.numpy() for k, v in g.items()}
-        pn = {k: v.numpy() for k, v in p.items()}
-        r = orc.forward_batched(gn, pn, zf.numpy(), zh.numpy(), factor, dt)
-        return {k: torch.from_numpy(numpy.ascontiguousarray(v)) for k, v in r.items()}
-
-    def backward(self, g, zf, p, factor, dt, Zf=None, **kw):
-        from oracle import spcpl_oracle as orc
-        gn = {k: v.numpy() for k, v in g.items()}
-        pn = {k: v.numpy() for k, v in p.items()}
-        r = orc.backward_batched(gn, Zf.numpy(), pn, zf.numpy(), factor, dt)
-        return {k: torch.from_numpy(numpy.ascontiguousarray(v)) for k, v in r.items()
-                if k.startswith("f_") or k == "start_index"}
+from tests.fake_engine import OracleEngine        # TEST-ONLY stand-in for sp_coupler_amd.engine.Engine on a GPU-less box
 
 
 def _worker(rank, world, port, n_cols, outdir):
@@ -63,9 +46,11 @@ def _worker(rank, world, port, n_cols, outdir):
         ex = sharding.ShardedExchange(OracleEngine(), n_cols, rank, world)
         g, zf_d, zh_d, p = ex.upload(gcm, zf, zh, prof)
         assert g["T"].shape[0] == ex.hi - ex.lo
-        fwd, bwd = ex.exchange(g, zf_d, zh_d, p, 1.0, 1.0, 900.0)
+        fwd, bwd = ex.exchange(g, zf_d, zh_d, p, 0.5, 0.5, 450.0)          # builds the lean plans ...
+        fwd, bwd = ex.exchange(g, zf_d, zh_d, p, 1.0, 1.0, 900.0)          # ... and relaunches them with new scalars
+        assert "Zf" not in fwd and "u" not in fwd                           # the lean K1: no optional outputs
         full = ex.gather({"f_thl": fwd["f_thl"], "idx": fwd["idx"], "f_ps": fwd["f_ps"], "f_T": bwd["f_T"],
-                          "start_index": bwd["start_index"]})
+                          "f_A": bwd["f_A"]})
         dist.barrier()
         if rank == 0:
             numpy.savez(os.path.join(outdir, "gathered.npz"), **full)
@@ -93,4 +78,4 @@ def test_sharded_exchange_gathers_same_result_as_single_rank(tmp_path, world, n_
     b = orc.backward_batched(gcm, f["Zf"], prof, zf, 1.0, 900.0)
     assert numpy.array_equal(got["f_thl"], f["f_thl"]) and numpy.array_equal(got["idx"], f["idx"])
     assert numpy.array_equal(got["f_ps"], f["f_ps"]) and numpy.array_equal(got["f_T"], b["f_T"], equal_nan=True)
-    assert numpy.array_equal(got["start_index"], b["start_index"])
+    assert numpy.array_equal(got["f_A"], b["f_A"], equal_nan=True)

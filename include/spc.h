@@ -168,8 +168,11 @@ int spc_surface_fluxes_f32(int64_t n, const void *Ph_s, const void *T_s, const v
  *   3 additive branch skipped (ql_ref <= ql_av), 4 no bracket -> beta_max; bit 8: brentq sign error (the reference
  *   raises ValueError there), bit 9: no convergence in 100 iterations (RuntimeError).
  * R: [n_cols][itot*jtot] the zero-mean Gaussian field of spcpl.py:620-621, drawn by the caller.  At most 32 767
- * columns per call.  Planes of up to ~9 000 points are solved from the CU's LDS (three launches), larger ones by a
- * kernel that sweeps them from memory; results are bit-identical either way.                                        */
+ * columns per call.  With the workspace (`work`) planes of up to ~9 000 points (KT levels x itot*jtot x 16 B <= 150 KiB of
+ * LDS, e.g. 64 x 64, 90 x 90) are solved from the CU's LDS and larger ones (96 x 96, 128 x 128, 256 x 256 ...) by one
+ * workgroup per level streaming its contiguous transposed planes; the update and qt.std are two further launches.
+ * Without the workspace small planes are loaded strided and large ones swept by a slower kernel; results are
+ * bit-identical on every path.                                                                                    */
 typedef struct spc_vnudge_args {
     int64_t n_cols;
     int32_t itot, jtot, ktot;
@@ -205,9 +208,9 @@ int spc_pick_cols_per_block(const spc_dims *dims, int pass);
  * dispatch table and require that every instantiation it reaches is bit-checked (tests/test_dispatch_gpu.py).
  * Writes at most buflen-1 characters + NUL; returns the length of the full text or a negative spc_status. */
 int spc_describe_launch(const spc_dims *dims, int pass, int flags, int elem_size, char *buf, int buflen);
-/* Bytes of spc_vnudge_args.work the LDS path of spc_variability_nudge_f64 wants for these extents
- * (n_cols*2*itot*jtot*ktot*8), or 0 when the planes do not fit the LDS and the sweeping kernel -- which uses no
- * workspace -- runs; negative spc_status on bad extents. */
+/* Bytes of spc_vnudge_args.work spc_variability_nudge_f64 wants for these extents (n_cols*2*itot*jtot*ktot*8: qt and
+ * qsat transposed to contiguous planes), 0 when the workspace-free kernels were forced (SPC_VN_LDS=0 /
+ * SPC_VN_TRANSPOSE=0, A/B runs); negative spc_status on bad extents. */
 int64_t spc_vnudge_workspace_bytes(int64_t n_cols, int32_t itot, int32_t jtot, int32_t ktot);
 
 #ifdef __cplusplus

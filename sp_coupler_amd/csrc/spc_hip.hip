@@ -1381,8 +1381,7 @@ int64_t spc_vnudge_workspace_bytes(int64_t n_cols, int32_t itot, int32_t jtot, i
 {
     if (n_cols < 0 || itot < 1 || jtot < 1 || ktot < 1 || (int64_t)itot * jtot > INT32_MAX / 2)
         return fail(SPC_ERR_INVALID_ARGUMENT, "%svariability_nudge: bad extents");
-    int kt, log2_kt, nleaf_max;
-    if (!vn_lds_fit(itot * jtot, &kt, &log2_kt, &nleaf_max) || !env_int("SPC_VN_TRANSPOSE", 1)) return 0;
+    if (!env_int("SPC_VN_LDS", 1) || !env_int("SPC_VN_TRANSPOSE", 1)) return 0;     // the sweeping kernel uses no workspace
     return n_cols * 2 * (int64_t)itot * jtot * ktot * 8;
 }
 
@@ -1405,14 +1404,23 @@ int spc_variability_nudge_f64(const spc_vnudge_args *a, void *stream)
     p.qt_std = (double *)a->qt_std; p.status = a->status;
     // Planes that fit the LDS (KT levels x nij x 16 B <= 150 KiB, KT a power of two <= 16; 64 x 64 planes: KT = 2)
     // are solved there (spc_vnudge2.hpp); larger planes (> ~9 000 points) keep the sweeping kernel.  SPC_VN_LDS=0: A/B.
+    // Where the planes live while the root finder runs: in the CU's LDS when KT levels' planes fit (KT x nij x 16 B <= 150
+    // KiB: up to ~9 000 points; 64 x 64 planes: KT = 2), else -- 128 x 128 and up -- in the caller's transposed workspace,
+    // one workgroup per level streaming its contiguous planes (k_vnudge_solve<true>).  Without a workspace large planes keep
+    // the sweeping kernel k_vnudge.  SPC_VN_LDS=0 forces the latter (A/B, tests).
     int kt, log2_kt, nleaf_max;
-    if (vn_lds_fit(p.nij, &kt, &log2_kt, &nleaf_max)) {
-        auto lds_need = [&](int t) { return vn_lds_need(p.nij, nleaf_max, t); };
+    const bool lds = vn_lds_fit(p.nij, &kt, &log2_kt, &nleaf_max);
+    const int64_t work_need = a->n_cols * 2 * (int64_t)p.nij * a->ktot * 8;
+    const bool have_work = a->work && a->work_bytes >= work_need && env_int("SPC_VN_TRANSPOSE", 1);
+    const bool global = !lds && have_work && env_int("SPC_VN_LDS", 1) && env_int("SPC_VN_GLOBAL", 1);
+    if (lds || global) {
+        auto lds_need = [&](int t) { return global ? (size_t)t * nleaf_max * 8 + VN2_THREADS * 12 : vn_lds_need(p.nij, nleaf_max, t); };
         // many workgroups (more than two rounds of one per CU): half the levels and half the threads per workgroup where
         // that lets TWO workgroups share a CU's LDS -- one's barriers and serial steps overlap the other's sums
         int nthreads = VN2_THREADS;
+        if (global) { kt = 1; log2_kt = 0; }
         const int pair = env_int("SPC_VN_PAIR", 1);       // 0 never, 1 by workgroup count, 2 always (tests)
-        if (kt > 1 && lds_need(kt / 2) <= (size_t)(78 * 1024) &&
+        if (!global && kt > 1 && lds_need(kt / 2) <= (size_t)(78 * 1024) &&
             (pair == 2 || (pair == 1 && a->n_cols * (int64_t)((a->ktot + kt - 1) / kt) > 512))) {
             kt >>= 1; --log2_kt; nthreads = VN2_THREADS / 2;
         }
@@ -1425,8 +1433,7 @@ int spc_variability_nudge_f64(const spc_vnudge_args *a, void *stream)
             q.tab.nround[shape] = vn_build_rounds(q.tab.nleaf[shape], q.tab.pl[shape], q.tab.pr[shape], q.tab.rnd[shape], ready);
         }
         q.work = nullptr;
-        const int64_t work_need = a->n_cols * 2 * (int64_t)p.nij * a->ktot * 8;
-        if (a->work && a->work_bytes >= work_need && env_int("SPC_VN_TRANSPOSE", 1)) {
+        if (have_work) {
             hipLaunchKernelGGL(k_vnudge_transpose, dim3((unsigned)((p.nij + 63) / 64), (unsigned)((a->ktot + 15) / 16), (unsigned)(a->n_cols * 2)),
                                dim3(256), 0, (hipStream_t)stream, p, (double *)a->work);
             int rct = launch_status("k_vnudge_transpose");
@@ -1438,15 +1445,33 @@ int spc_variability_nudge_f64(const spc_vnudge_args *a, void *stream)
         q.gpc = (q.tiles + q.tg - 1) / q.tg;
         q.groups = a->n_cols * q.gpc;
         const size_t smem = lds_need(kt);
-        int rc = ensure_lds(k_vnudge_solve, smem, "variability_nudge");
+        int rc = global ? ensure_lds(k_vnudge_solve<true>, smem, "variability_nudge") : ensure_lds(k_vnudge_solve<false>, smem, "variability_nudge");
         if (rc) return rc;
         const int64_t nblk = (q.groups + 7) / 8 * 8 * q.tg;
         if (nblk > INT32_MAX) return fail(SPC_ERR_UNSUPPORTED, "%svariability_nudge: too many workgroups");
-        hipLaunchKernelGGL(k_vnudge_solve, dim3((unsigned)nblk), dim3(nthreads), smem, (hipStream_t)stream, q);
+        if (global)
+            hipLaunchKernelGGL(k_vnudge_solve<true>, dim3((unsigned)nblk), dim3(nthreads), smem, (hipStream_t)stream, q);
+        else
+            hipLaunchKernelGGL(k_vnudge_solve<false>, dim3((unsigned)nblk), dim3(nthreads), smem, (hipStream_t)stream, q);
         rc = launch_status("k_vnudge_solve");
         if (rc) return rc;
-        hipLaunchKernelGGL(k_vnudge_apply, dim3((unsigned)((a->ktot + 15) / 16), (unsigned)a->n_cols), dim3(256), 0, (hipStream_t)stream, p);
-        return launch_status("k_vnudge_apply");
+        // the update (elementwise, wide) and qt.std (ordered sums, 16 levels per workgroup)
+        const size_t usmem = (size_t)a->ktot * (3 * sizeof(double) + sizeof(int));
+        if ((rc = ensure_lds(k_vnudge_update, usmem, "variability_nudge (update)"))) return rc;
+        hipLaunchKernelGGL(k_vnudge_update, dim3((unsigned)((p.nij + VU_ROWS - 1) / VU_ROWS), (unsigned)a->n_cols), dim3(256), usmem,
+                           (hipStream_t)stream, p);
+        if ((rc = launch_status("k_vnudge_update"))) return rc;
+        const dim3 sgrid((unsigned)((a->ktot + 15) / 16), (unsigned)a->n_cols);
+        if ((int64_t)sgrid.x * sgrid.y <= 256 && env_int("SPC_VN_STD_ROWS", 512) == 512) {
+            const size_t ssmem = (size_t)2 * 512 * 16 * sizeof(double);
+            if ((rc = ensure_lds(k_vnudge_std<512>, ssmem, "variability_nudge (std)"))) return rc;
+            hipLaunchKernelGGL(k_vnudge_std<512>, sgrid, dim3(VS_THREADS), ssmem, (hipStream_t)stream, p);
+        } else {
+            const size_t ssmem = (size_t)2 * 256 * 16 * sizeof(double);
+            if ((rc = ensure_lds(k_vnudge_std<256>, ssmem, "variability_nudge (std)"))) return rc;
+            hipLaunchKernelGGL(k_vnudge_std<256>, sgrid, dim3(VS_THREADS), ssmem, (hipStream_t)stream, p);
+        }
+        return launch_status("k_vnudge_std");
     }
     hipLaunchKernelGGL(k_vnudge, dim3((unsigned)((a->ktot + VN_KT - 1) / VN_KT), (unsigned)a->n_cols), dim3(64 * VN_WAVES), 0, (hipStream_t)stream, p);
     return launch_status("k_vnudge");

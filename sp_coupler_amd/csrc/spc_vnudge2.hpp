@@ -83,7 +83,12 @@ __host__ __device__ inline int vn_build_rounds(int nleaf, const unsigned short *
     return nr;
 }
 
-__global__ __launch_bounds__(VN2_THREADS) void k_vnudge_solve(const Vn2P q)
+// GLOBAL = false: the planes of the workgroup's KT levels are copied into LDS once and every evaluation runs from there
+// (planes of up to ~9 000 points).  GLOBAL = true: planes too large for the LDS (128 x 128 and up -- ordinary DALES sizes)
+// stay in the caller's transposed workspace, contiguous per level, and every evaluation streams them from L2 / the
+// Infinity Cache with coalesced 64-B-per-leaf-group reads: one workgroup per level (KT = 1), i.e. n_cols x ktot workgroups
+// instead of the sweeping kernel's n_cols x ktot / 16, and no strided [ij][k] access.  Same sums, same order, same bits.
+template <bool GLOBAL> __global__ __launch_bounds__(VN2_THREADS) void k_vnudge_solve(const Vn2P q)
 {
     const VnP &p = q.p;
     extern __shared__ __align__(16) unsigned char vn2_smem[];
@@ -113,12 +118,17 @@ __global__ __launch_bounds__(VN2_THREADS) void k_vnudge_solve(const Vn2P q)
     const bool valid = k < ktot;
     const bool own = tl == 0;
     const int npl = vn2_plane(nij);                                            // skewed plane length
-    double *const s_qt = reinterpret_cast<double *>(vn2_smem);               // [KT][npl]
-    double *const s_qs = s_qt + (size_t)KT * npl;                              // [KT][npl]
-    double *const s_leaf = s_qs + (size_t)KT * npl;                            // [KT][nleaf_max]
+    double *const s_qt = reinterpret_cast<double *>(vn2_smem);               // [KT][npl]   (GLOBAL: no planes in LDS)
+    double *const s_qs = s_qt + (GLOBAL ? 0 : (size_t)KT * npl);                // [KT][npl]
+    double *const s_leaf = s_qs + (GLOBAL ? 0 : (size_t)KT * npl);              // [KT][nleaf_max]
     double *const s_part = s_leaf + (size_t)KT * q.nleaf_max;                  // [VN2_THREADS] argmax values
     int *const s_parti = reinterpret_cast<int *>(s_part + VN2_THREADS);        // [VN2_THREADS] argmax indices
-    double *const my_qt = s_qt + (size_t)kl * npl, *const my_qs = s_qs + (size_t)kl * npl, *const my_leaf = s_leaf + (size_t)kl * q.nleaf_max;
+    double *const my_leaf = s_leaf + (size_t)kl * q.nleaf_max;
+    const int kq_ = (k < ktot) ? k : ktot - 1;
+    // this level's planes: LDS copies (skewed, vn2_pos) or the contiguous planes of the transposed workspace
+    const double *const my_qt = GLOBAL ? q.work + ((col * 2 + 0) * (int64_t)ktot + kq_) * nij : s_qt + (size_t)kl * npl;
+    const double *const my_qs = GLOBAL ? q.work + ((col * 2 + 1) * (int64_t)ktot + kq_) * nij : s_qs + (size_t)kl * npl;
+    auto POS = [](int e) { return GLOBAL ? e : vn2_pos(e); };
 
     {   // the host-built tree tables: argument block -> LDS, one 4-byte word per lane
         static_assert(sizeof(Vn2Tables) % 4 == 0, "Vn2Tables is copied by words");
@@ -129,14 +139,16 @@ __global__ __launch_bounds__(VN2_THREADS) void k_vnudge_solve(const Vn2P q)
     }
 
     // ---- planes -> LDS ---------------------------------------------------------------------------------------------------
-    if (q.work) {                                   // transposed workspace: every level's group streams its own planes
+    if constexpr (GLOBAL) {
+    } else if (q.work) {                            // transposed workspace: every level's group streams its own planes
         const int kq = valid ? k : ktot - 1;
         const double *const wq = q.work + ((col * 2 + 0) * (int64_t)ktot + kq) * nij;
         const double *const ws = q.work + ((col * 2 + 1) * (int64_t)ktot + kq) * nij;
+        double *const dq = s_qt + (size_t)kl * npl, *const ds = s_qs + (size_t)kl * npl;
 #pragma unroll 4
         for (int ij = tl; ij < nij; ij += TL) {
-            my_qt[vn2_pos(ij)] = wq[ij];
-            my_qs[vn2_pos(ij)] = ws[ij];
+            dq[vn2_pos(ij)] = wq[ij];
+            ds[vn2_pos(ij)] = ws[ij];
         }
     } else {                                        // [ij][k] order: element e = (ij, level of the tile), levels fastest
         const int64_t base = col * (int64_t)nij * ktot;
@@ -178,9 +190,9 @@ __global__ __launch_bounds__(VN2_THREADS) void k_vnudge_solve(const Vn2P q)
         double bv = 0.0;
         int bi = -1;
         if (s_mode[kl] == 3 && lo < hi) {
-            bi = lo; bv = my_qt[vn2_pos(lo)] - my_qs[vn2_pos(lo)];
+            bi = lo; bv = my_qt[POS(lo)] - my_qs[POS(lo)];
             for (int ij = lo + 1; ij < hi && !(bv != bv); ++ij) {
-                const double v = my_qt[vn2_pos(ij)] - my_qs[vn2_pos(ij)];
+                const double v = my_qt[POS(ij)] - my_qs[POS(ij)];
                 if (v > bv || v != v) { bv = v; bi = ij; }
             }
         }
@@ -194,7 +206,7 @@ __global__ __launch_bounds__(VN2_THREADS) void k_vnudge_solve(const Vn2P q)
                 const double v = s_part[tid + w];
                 if (qi >= 0 && (v > best || v != v)) { best = v; idx = qi; }
             }
-            beta = (my_qs[vn2_pos(idx)] - qt_av) / (my_qt[vn2_pos(idx)] - qt_av);  // spcpl.py:683
+            beta = (my_qs[POS(idx)] - qt_av) / (my_qt[POS(idx)] - qt_av);          // spcpl.py:683
             if (beta < 0) beta = 1.0;                                                // spcpl.py:692-695
             st = VN_UNSAT;
         }
@@ -255,8 +267,13 @@ __global__ __launch_bounds__(VN2_THREADS) void k_vnudge_solve(const Vn2P q)
                     } else {
                         const int cnt = n >> 3, n8 = cnt << 3;
                         double r = term(lo + acc);
+                        if constexpr (GLOBAL) {
+#pragma unroll 15
+                            for (int i = 1; i < cnt; ++i) r += term(lo + 8 * i + acc);
+                        } else {
 #pragma unroll 4
-                        for (int i = 1; i < cnt; ++i) r += term(lo + 8 * i + acc);
+                            for (int i = 1; i < cnt; ++i) r += term(lo + 8 * i + acc);
+                        }
                         r = r + __shfl_down(r, 1, 8);               // lanes 0,2,4,6: r0+r1, r2+r3, r4+r5, r6+r7
                         r = r + __shfl_down(r, 2, 8);               // lanes 0,4: (r0+r1)+(r2+r3), (r4+r5)+(r6+r7)
                         r = r + __shfl_down(r, 4, 8);               // lane 0: the leaf's 8-accumulator sum
@@ -269,13 +286,13 @@ __global__ __launch_bounds__(VN2_THREADS) void k_vnudge_solve(const Vn2P q)
             };
             if (mode == 1)
                 leaves([&](int ij) {
-                    const int e = vn2_pos(c0 + ij);
+                    const int e = POS(c0 + ij);
                     const double t = ((x * (my_qt[e] - qt_av)) + qt_av) - my_qs[e];
                     return (t >= 0.0 || t != t) ? t : 0.0;                           // numpy.maximum(t, 0)
                 });
             else if (mode == 2)
                 leaves([&](int ij) {
-                    const int e = vn2_pos(c0 + ij);
+                    const int e = POS(c0 + ij);
                     const double t = (my_qt[e] + (x * R[c0 + ij])) - my_qs[e];
                     return (t >= 0.0 || t != t) ? t : 0.0;
                 });
@@ -338,93 +355,156 @@ __global__ __launch_bounds__(VN2_THREADS) void k_vnudge_solve(const Vn2P q)
     }
 }
 
-// K6b: qt (and thl with constantT) of every touched level, then qt.std(axis=(0, 1)) (spcpl.py:741): numpy reduces over
-// (i, j) with k as the inner loop, i.e. plain SEQUENTIAL sums in C order (mean = sum/N, then sum((x - mean)^2)/N, sqrt).
-// A workgroup owns 16 consecutive levels of one column (one 128-B line per (i, j) row) and streams the plane rows
-// through an LDS tile: all 256 threads load / update / store coalesced rows (16 lanes along k x 16 rows at a time, 8 rows
-// in flight per thread), then the 16 lanes of the first half-wave add the tile's rows to their level's sum IN ORDER from
-// LDS while the next tile's loads are in flight.  The mean's sum rides on the apply sweep; a second sweep re-reads the
-// updated qt for the variance.
-constexpr int VB_ROWS = 128;      // (i, j) rows per tile: 16 KiB of LDS, two tiles (ping-pong)
-__global__ __launch_bounds__(256) void k_vnudge_apply(const VnP p)
+// K6b: qt (and thl with constantT) of every touched level (spcpl.py:716-733).  Elementwise, no order constraint: as many
+// workgroups as the data allows (a workgroup takes VU_ROWS (i, j) rows of one column; 32 lanes along k, the fastest
+// index of the reference's [ij][k] layout, 8 rows at a time), levels that need nothing are neither read nor written.
+constexpr int VU_ROWS = 64;
+__global__ __launch_bounds__(256) void k_vnudge_update(const VnP p)
 {
-    __shared__ double s_tile[2][VB_ROWS][16];
+    extern __shared__ __align__(16) unsigned char vu_smem[];
+    const int ktot = p.ktot, nij = p.nij, tid = threadIdx.x;
+    double *const s_coef = reinterpret_cast<double *>(vu_smem);          // [ktot] beta - 1 or a
+    double *const s_av = s_coef + ktot;                                    // [ktot] qt_av
+    double *const s_tc = s_av + ktot;                                      // [ktot] -rlv / (cp exner(presf)), constantT
+    int *const s_ap = reinterpret_cast<int *>(s_tc + ktot);               // [ktot] 0 nothing, 1 multiplicative, 2 additive, +4 thl
+    __shared__ int s_any;
+    const int64_t col = blockIdx.y;
+    if (tid == 0) s_any = 0;
+    __syncthreads();
+    for (int k = tid; k < ktot; k += 256) {
+        const int64_t lev = col * ktot + k;
+        const int stv = p.status[lev];
+        const int ap = (stv & VN2_APPLY_MULT) ? 1 : ((stv & VN2_APPLY_ADD) ? 2 : 0);
+        const bool th = p.constantT && (stv & VN2_TOUCHED);
+        s_coef[k] = ap == 1 ? p.beta[lev] - 1 : p.a_add[lev];
+        s_av[k] = p.qt_av[lev];
+        s_tc[k] = th ? (-K<double>::rlv) / (K<double>::cp * spc_pow(div_pref0(p.presf[lev]), K<double>::rd / K<double>::cp)) : 0.0;   // spcpl.py:731
+        s_ap[k] = ap | (th ? 4 : 0);
+        if (ap | (th ? 4 : 0)) s_any = 1;
+    }
+    __syncthreads();
+    if (!s_any) return;
+    const int kq = tid & 31, rq = tid >> 5;
+    const int ij0 = blockIdx.x * VU_ROWS, ij1 = (ij0 + VU_ROWS) < nij ? (ij0 + VU_ROWS) : nij;
+    const int64_t base = col * (int64_t)nij * ktot;
+    const double *const R = p.R + col * (int64_t)nij;
+    for (int k = kq; k < ktot; k += 32) {
+        const int ap = s_ap[k];
+        if (!ap) continue;
+        const double coef = s_coef[k], qt_av = s_av[k], tc = s_tc[k];
+#pragma unroll 4
+        for (int ij = ij0 + rq; ij < ij1; ij += 8) {
+            const int64_t g = base + (int64_t)ij * ktot + k;
+            double v = p.qt[g];
+            if ((ap & 3) == 1) { v = v + coef * (v - qt_av); p.qt[g] = v; }                  // spcpl.py:724-725
+            else if ((ap & 3) == 2) { v = v + coef * R[ij]; p.qt[g] = v; }                  // spcpl.py:716-719
+            if (ap & 4) {                                                                   // spcpl.py:726-733
+                const double tt = v - p.qsat[g];
+                const double ql_target = (tt >= 0.0 || tt != tt) ? tt : 0.0;
+                p.thl[g] += tc * (ql_target - p.ql[g]);
+            }
+        }
+    }
+}
+
+// K6c: qt.std(axis=(0, 1)) (spcpl.py:741): numpy reduces over (i, j) with k as the inner loop, i.e. plain SEQUENTIAL sums
+// in C order (mean = sum/N, then sum((x - mean)^2)/N, sqrt).  The order binds the ADDS, not the loads: a workgroup owns
+// 16 consecutive levels of one column (one 128-B line per (i, j) row).  Waves 1-4 (256 threads) only LOAD: tiles of ROWS
+// rows (ROWS / 16 rows per thread in flight, unconditional loads at clamped indices) into an LDS ping-pong; wave 0 only
+// ADDS: its first 16 lanes take tile t's rows IN ORDER from LDS -- reads software-pipelined 16 rows ahead of the dependent
+// add chain -- while tile t + 1 sits in the other buffer and the loads of tile t + 2 are in flight.  (Round 2's kernel
+// kept ONE 128-row tile in flight per workgroup, its summing wave also loaded, and it was bound by the load latency of
+// each tile: 143 us for a 64 x 64 x 160 LES even when no level needed a nudge.)  ROWS = 512 (128 KiB of LDS, one
+// workgroup per CU) for few workgroups, 256 for many.
+constexpr int VS_THREADS = 320;
+template <int ROWS> __global__ __launch_bounds__(VS_THREADS) void k_vnudge_std(const VnP p)
+{
+    extern __shared__ __align__(16) unsigned char vs_smem[];
+    double (*const s_tile)[ROWS][16] = reinterpret_cast<double (*)[ROWS][16]>(vs_smem);      // [2][ROWS][16]
     __shared__ double s_mean[16];
-    constexpr int U = VB_ROWS / 16;                      // rows per thread and tile, all in flight together
-    const int lane = threadIdx.x & 15, row = threadIdx.x >> 4;
+    constexpr int U = ROWS / 16;                         // rows per loader thread and tile, all in flight together
+    const int tid = threadIdx.x;
+    const bool adder = tid < 64;                         // wave 0; its lanes 0..15 carry one level each
+    const int lt = adder ? tid : tid - 64;
+    const int lane = lt & 15, row = lt >> 4;
     const int64_t col = blockIdx.y;
     const int k = blockIdx.x * 16 + lane, nij = p.nij;
     const bool valid = k < p.ktot;
-    const int kk = valid ? k : p.ktot - 1;
+    const int kk = valid ? k : p.ktot - 1;               // in-bounds addresses for the lanes past the last level
     const int64_t lev = col * p.ktot + kk, ks = p.ktot, base = col * (int64_t)nij * ks + kk;
-    double *const qt = p.qt + base;
-    const double *const qsat = p.qsat + base, *const R = p.R + col * (int64_t)nij;
-    const int stv = p.status[lev];
-    const int ap = (stv & VN2_APPLY_MULT) ? 1 : ((stv & VN2_APPLY_ADD) ? 2 : 0);
-    const bool tch = (stv & VN2_TOUCHED) != 0;
-    const double coef = ap == 1 ? p.beta[lev] - 1 : p.a_add[lev], qt_av = p.qt_av[lev];
-    double *const thl = (p.constantT && tch) ? p.thl + base : nullptr;
-    const double *const ql = (p.constantT && tch) ? p.ql + base : nullptr;
-    double tc = 0.0;
-    if (thl) tc = (-K<double>::rlv) / (K<double>::cp * spc_pow(div_pref0(p.presf[lev]), K<double>::rd / K<double>::cp));   // spcpl.py:731
-    const int ntile = (nij + VB_ROWS - 1) / VB_ROWS;
-    auto load_tile = [&](int t, double (&v)[U]) {
+    const double *const qt = p.qt + base;
+    const int ntile = (nij + ROWS - 1) / ROWS;
+    double w[U];
+    auto load_tile = [&](int t) {                        // rows past the plane's end re-read its last row: never added
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int ij = t * VB_ROWS + row + 16 * u;
-            v[u] = (valid && ij < nij) ? qt[(int64_t)ij * ks] : 0.0;
+            const int ij = t * ROWS + row + 16 * u;
+            w[u] = qt[(int64_t)(ij < nij ? ij : nij - 1) * ks];
         }
     };
-
-    // One barrier per tile: tile t goes to s_tile[t & 1], the loads of tile t + 1 are issued, and only then do the 16
-    // lanes of row 0 add tile t's rows IN ORDER (the other buffer was last read before the previous barrier).
-    double s = 0.0, v[U], w[U];
-    load_tile(0, v);
-    for (int t = 0; t < ntile; ++t) {
-        const int nr = (nij - t * VB_ROWS) < VB_ROWS ? (nij - t * VB_ROWS) : VB_ROWS;
+    auto store_tile = [&](int t) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int r = row + 16 * u, ij = t * VB_ROWS + r;
-            if (valid && r < nr) {
-                if (ap == 1) { v[u] = v[u] + coef * (v[u] - qt_av); qt[(int64_t)ij * ks] = v[u]; }          // spcpl.py:724-725
-                else if (ap == 2) { v[u] = v[u] + coef * R[ij]; qt[(int64_t)ij * ks] = v[u]; }             // spcpl.py:716-719
-                if (thl) {                                                                                  // spcpl.py:726-733
-                    const double tt = v[u] - qsat[(int64_t)ij * ks];
-                    const double ql_target = (tt >= 0.0 || tt != tt) ? tt : 0.0;
-                    thl[(int64_t)ij * ks] += tc * (ql_target - ql[(int64_t)ij * ks]);
+        for (int u = 0; u < U; ++u) s_tile[t & 1][row + 16 * u][lane] = w[u];
+    };
+    double mean = 0.0, acc = 0.0;
+    for (int pass = 0; pass < 2; ++pass) {               // pass 0: sum -> mean; pass 1: sum of squared deviations
+        acc = 0.0;
+        if (!adder) {
+            load_tile(0);
+            store_tile(0);
+            if (ntile > 1) load_tile(1);
+        }
+        __syncthreads();
+        for (int t = 0; t < ntile; ++t) {
+            if (adder) {
+                if (row == 0) {
+                    const int nr = (nij - t * ROWS) < ROWS ? (nij - t * ROWS) : ROWS;
+                    const double (*const tl)[16] = s_tile[t & 1];
+                    double a[16], b[16];
+                    int r0 = 0;
+                    if (nr >= 16) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) a[i] = tl[i][lane];
+                    }
+                    for (; r0 + 32 <= nr; r0 += 32) {    // 16 rows being added while the next 16 are on their way from LDS
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) b[i] = tl[r0 + 16 + i][lane];
+                        if (pass == 1) {                                  // the squares first: off the dependent add chain
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) { const double dlt = a[i] - mean; a[i] = dlt * dlt; }
+                        }
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc += a[i];
+                        const int nx = (r0 + 48 <= ROWS) ? r0 + 32 : r0 + 16;        // stay inside the buffer
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) a[i] = tl[nx + i][lane];
+                        if (pass == 1) {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) { const double dlt = b[i] - mean; b[i] = dlt * dlt; }
+                        }
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc += b[i];
+                    }
+                    for (; r0 < nr; ++r0) {              // the tail of a ragged last tile
+                        const double x = tl[r0][lane];
+                        if (pass == 0) acc += x;
+                        else { const double dlt = x - mean; acc += dlt * dlt; }
+                    }
                 }
+            } else if (t + 1 < ntile) {
+                store_tile(t + 1);                        // the other buffer: its last reader (tile t - 1) finished before the last barrier
+                if (t + 2 < ntile) load_tile(t + 2);
             }
-            s_tile[t & 1][r][lane] = v[u];
+            __syncthreads();
         }
-        if (t + 1 < ntile) load_tile(t + 1, w);
-        __syncthreads();
-        if (row == 0) {
-#pragma unroll 8
-            for (int r = 0; r < nr; ++r) s += s_tile[t & 1][r][lane];
+        if (pass == 0) {
+            if (adder && row == 0) s_mean[lane] = acc / (double)nij;
+            __syncthreads();
+            mean = s_mean[lane];
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = w[u];
     }
-    if (row == 0) s_mean[lane] = s / (double)nij;
-    __syncthreads();
-    const double mean = s_mean[lane];
-    double var = 0.0;
-    load_tile(0, v);                                      // this thread's own stores of sweep 1
-    for (int t = 0; t < ntile; ++t) {
-        const int nr = (nij - t * VB_ROWS) < VB_ROWS ? (nij - t * VB_ROWS) : VB_ROWS;
-#pragma unroll
-        for (int u = 0; u < U; ++u) s_tile[t & 1][row + 16 * u][lane] = v[u];
-        if (t + 1 < ntile) load_tile(t + 1, w);
-        __syncthreads();
-        if (row == 0) {
-#pragma unroll 8
-            for (int r = 0; r < nr; ++r) { const double dlt = s_tile[t & 1][r][lane] - mean; var += dlt * dlt; }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = w[u];
-    }
-    if (row == 0 && valid) {
-        p.qt_std[lev] = sqrt(var / (double)nij);
-        p.status[lev] = stv & ~VN2_INTERNAL;
+    if (adder && row == 0 && valid) {
+        p.qt_std[lev] = sqrt(acc / (double)nij);
+        p.status[lev] = p.status[lev] & ~VN2_INTERNAL;
     }
 }

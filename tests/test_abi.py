@@ -119,7 +119,7 @@ def test_describe_launch_names_the_instantiation_the_launcher_would_pick(lib):
     with pytest.raises(_abi.SpcInvalidArgument):
         _abi.describe_launch(lib, d(10), 7, 0)
     assert lib.spc_vnudge_workspace_bytes(2, 64, 64, 160) == 2 * 2 * 64 * 64 * 160 * 8
-    assert lib.spc_vnudge_workspace_bytes(2, 128, 128, 160) == 0          # planes too large for the LDS path
+    assert lib.spc_vnudge_workspace_bytes(2, 128, 128, 160) == 2 * 2 * 128 * 128 * 160 * 8   # large planes stream from it
     assert lib.spc_vnudge_workspace_bytes(2, 0, 64, 160) < 0
 
 

@@ -146,8 +146,12 @@ def test_kernel_matches_the_numpy_scipy_oracle(constantT, lds, monkeypatch):
     monkeypatch.setenv("SPC_VN_LDS", "0" if lds == "0" else "1")
     monkeypatch.setenv("SPC_VN_PAIR", "2" if lds == "pair" else "1")            # two 256-thread workgroups per CU
     monkeypatch.setenv("SPC_VN_TRANSPOSE", "0" if lds == "strided" else "1")    # without the transposed workspace
-    shapes = [(16, 12, 40, 3), (9, 7, 23, 4), (64, 64, 160, 5), (96, 96, 12, 6), (32, 32, 24, 7), (64, 32, 21, 8), (90, 90, 12, 10)]
-    for group in ([0, 1], [2], [3], [4], [5], [6]):     # one launch per extent (a launch has one plane geometry)
+    shapes = [(16, 12, 40, 3), (9, 7, 23, 4), (64, 64, 160, 5), (96, 96, 12, 6), (32, 32, 24, 7), (64, 32, 21, 8), (90, 90, 12, 10),
+              (92, 92, 12, 11), (128, 128, 12, 12), (200, 170, 5, 13)]
+    # 92 x 92 = 8464 points: the LDS path with TWO chunks of numpy's 8192-element blocking; 96 x 96, 128 x 128 and 200 x 170
+    # (4 chunks + a ragged last one) do not fit the LDS: with the transposed workspace one workgroup per level streams the
+    # planes (k_vnudge_solve<true>), without it ("strided", "0") the sweeping kernel k_vnudge takes them
+    for group in ([0, 1], [2], [3], [4], [5], [6], [7], [8], [9]):     # one launch per extent (a launch has one plane geometry)
         fs = [make_les_fields(*shapes[g][:3], seed=shapes[g][3]) for g in group]
         if len(group) == 2:                             # same geometry needed inside one launch: pad the second to the first
             fs[1] = make_les_fields(*shapes[group[0]][:3], seed=shapes[group[1]][3])
@@ -161,7 +165,7 @@ def test_kernel_matches_the_numpy_scipy_oracle(constantT, lds, monkeypatch):
                                      constantT, thl=f["thl"], ql=f["ql"])
             assert r["error"] is None
             assert numpy.array_equal(g["status"], r["status"]), (g["status"], r["status"])
-            assert (r["status"] & 1).any() and (r["status"] & 4).any()
+            assert m.ktot < 12 or ((r["status"] & 1).any() and (r["status"] & 4).any())     # the data reach both root finders
             assert numpy.array_equal(g["beta"], r["beta"]) and numpy.array_equal(g["a"], r["a"])
             assert numpy.array_equal(m.fields.QT, r["qt"])
             assert numpy.array_equal(g["qt_std"], r["qt_std"]) and numpy.array_equal(g["alpha"], r["alpha"])

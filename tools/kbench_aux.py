@@ -37,11 +37,14 @@ def main():
     ap.add_argument("--levels", default="91,160")
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--vn-cols", default="2,64")
+    ap.add_argument("--vn-shapes", default="64x64x160", help="LES field extents itot x jtot x ktot, comma separated")
+    ap.add_argument("--vn-modes", default="default", help="default (LDS / streamed planes), sweep (SPC_VN_LDS=0: the sweeping kernel)")
+    ap.add_argument("--vn-iters", type=int, default=20)
     a = ap.parse_args()
     nG, nL = (int(x) for x in a.levels.split(","))
     eng = Engine("cuda:0")
     sptr = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    for n in (int(x) for x in a.sizes.split(",")):
+    for n in (int(x) for x in a.sizes.split(",") if x):
         gcm, zf, zh, prof = synthetic.make_batch_tiled(n, nG, nL, seed=77, couple_surface=False)
         g = {k: torch.from_numpy(v).cuda() for k, v in gcm.items()}
         p = {k: torch.from_numpy(v).cuda() for k, v in prof.items()}
@@ -59,23 +62,32 @@ def main():
         print("n=%d %d<->%d | K3 %.1f us %.0f GB/s | K4 (conservative) %.1f us %.0f GB/s (%.2fx K3) | K5 gcm-level %.1f us %.0f GB/s | "
               "K5 +les-level %.1f us %.0f GB/s" % (n, nG, nL, t3, b3 / t3 / 1e3, t4, b4 / t4 / 1e3, t4 / t3, t5a, b5a / t5a / 1e3,
                                                  t5b, b5b / t5b / 1e3), flush=True)
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     from tests.test_vnudge import make_les_fields
-    for ncol in (int(x) for x in a.vn_cols.split(",")):
-        f = make_les_fields(64, 64, 160, seed=5)
-        rep = lambda x: torch.from_numpy(numpy.ascontiguousarray(numpy.broadcast_to(x, (ncol,) + x.shape))).cuda()     # noqa: E731
-        qt0, qsat, thl0, ql = rep(f["qt"]), rep(f["qsat"]), rep(f["thl"]), rep(f["ql"])
-        R = torch.from_numpy(numpy.random.default_rng(1).normal(size=(ncol, 64, 64))).cuda()
-        prof = {k: rep(f[k]) for k in ("ql_av", "qt_av", "ql_ref", "presf")}
-        qt = qt0.clone()
+    for shape in (x for x in a.vn_shapes.split(",") if x):
+        it, jt, kt = (int(v) for v in shape.split("x"))
+        f = make_les_fields(it, jt, kt, seed=5)
+        for ncol in (int(x) for x in a.vn_cols.split(",") if x):
+            if ncol * it * jt * kt * 8 * 5 > 60e9:
+                continue
+            rep = lambda x: torch.from_numpy(numpy.ascontiguousarray(numpy.broadcast_to(x, (ncol,) + x.shape))).cuda()     # noqa: E731
+            qt0, qsat = rep(f["qt"]), rep(f["qsat"])
+            R = torch.from_numpy(numpy.random.default_rng(1).normal(size=(ncol, it, jt))).cuda()
+            prof = {k: rep(f[k]) for k in ("ql_av", "qt_av", "ql_ref", "presf")}
+            qt = qt0.clone()
 
-        def run():
-            qt.copy_(qt0)
-            eng.variability_nudge(qt, qsat, R, prof["ql_av"], prof["qt_av"], prof["ql_ref"])
-        t = timed(run, 20)
-        tc = timed(lambda: qt.copy_(qt0), 20)
-        print("K6 variability nudge: %d LES of 64x64x160: %.0f us per launch (%.0f us of it the qt reset copy); "
-              "the reference's brentq over NumPy: see tests" % (ncol, t, tc), flush=True)
+            def run():
+                qt.copy_(qt0)
+                eng.variability_nudge(qt, qsat, R, prof["ql_av"], prof["qt_av"], prof["ql_ref"])
+            for mode in a.vn_modes.split(","):
+                os.environ["SPC_VN_LDS"] = "0" if mode == "sweep" else "1"
+                t = timed(run, a.vn_iters)
+                tc = timed(lambda: qt.copy_(qt0), a.vn_iters)
+                print("K6 variability nudge [%s]: %d LES of %dx%dx%d: %.0f us per launch (%.0f us of it the qt reset copy)"
+                      % (mode, ncol, it, jt, kt, t, tc), flush=True)
+            os.environ.pop("SPC_VN_LDS", None)
+            del qt0, qsat, qt, R, prof
+            eng._vn_work = None
+            torch.cuda.empty_cache()
 
 
 if __name__ == "__main__":

@@ -7,10 +7,11 @@ from sp_coupler_amd.engine import Engine
 from tests.test_vnudge import make_les_fields
 eng = Engine("cuda:0")
 ncol = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-f = make_les_fields(64, 64, 160, seed=5)
+IT, JT, KT = (int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "64x64x160").split("x"))
+f = make_les_fields(IT, JT, KT, seed=5)
 rep = lambda x: torch.from_numpy(numpy.ascontiguousarray(numpy.broadcast_to(x, (ncol,) + x.shape))).cuda()
 qt0, qsat = rep(f["qt"]), rep(f["qsat"])
-R = torch.from_numpy(numpy.random.default_rng(1).normal(size=(ncol, 64, 64))).cuda()
+R = torch.from_numpy(numpy.random.default_rng(1).normal(size=(ncol, IT, JT))).cuda()
 for name, ql_ref, ql_av in (("synthetic", f["ql_ref"], f["ql_av"]), ("idle", f["ql_ref"] * 0, f["ql_av"] * 0)):
     prof = {"ql_av": rep(ql_av), "qt_av": rep(f["qt_av"]), "ql_ref": rep(ql_ref)}
     for i in range(5):

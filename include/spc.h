@@ -171,8 +171,8 @@ int spc_surface_fluxes_f32(int64_t n, const void *Ph_s, const void *T_s, const v
  * columns per call.  With the workspace (`work`) planes of up to ~9 000 points (KT levels x itot*jtot x 16 B <= 150 KiB of
  * LDS, e.g. 64 x 64, 90 x 90) are solved from the CU's LDS and larger ones (96 x 96, 128 x 128, 256 x 256 ...) by one
  * workgroup per level streaming its contiguous transposed planes; the update and qt.std are two further launches.
- * Without the workspace small planes are loaded strided and large ones swept by a slower kernel; results are
- * bit-identical on every path.                                                                                    */
+ * Without the workspace planes that fit the LDS are loaded strided (slower) and larger ones are refused
+ * (SPC_ERR_INVALID_ARGUMENT); results are bit-identical on every path.                                            */
 typedef struct spc_vnudge_args {
     int64_t n_cols;
     int32_t itot, jtot, ktot;
@@ -186,8 +186,8 @@ typedef struct spc_vnudge_args {
     const void *ql_ref;                /* [n][ktot] les.ql_ref (K1's ql_ref output)                           */
     void *beta, *a_add, *qt_std;       /* [n][ktot] outputs                                                   */
     int32_t *status;                   /* [n][ktot] output                                                    */
-    void *work;                        /* optional device scratch of work_bytes >= n*2*itot*jtot*ktot*8 (ABI 2): qt and  */
-    int64_t work_bytes;                /* qsat transposed to contiguous planes, 8x fewer memory requests; NULL = without */
+    void *work;                        /* device scratch of work_bytes >= spc_vnudge_workspace_bytes(): qt and qsat as  */
+    int64_t work_bytes;                /* contiguous planes; optional (NULL) only for planes that fit the LDS           */
 } spc_vnudge_args;
 
 int spc_variability_nudge_f64(const spc_vnudge_args *args, void *stream);
@@ -209,8 +209,8 @@ int spc_pick_cols_per_block(const spc_dims *dims, int pass);
  * Writes at most buflen-1 characters + NUL; returns the length of the full text or a negative spc_status. */
 int spc_describe_launch(const spc_dims *dims, int pass, int flags, int elem_size, char *buf, int buflen);
 /* Bytes of spc_vnudge_args.work spc_variability_nudge_f64 wants for these extents (n_cols*2*itot*jtot*ktot*8: qt and
- * qsat transposed to contiguous planes), 0 when the workspace-free kernels were forced (SPC_VN_LDS=0 /
- * SPC_VN_TRANSPOSE=0, A/B runs); negative spc_status on bad extents. */
+ * qsat transposed to contiguous planes; required for planes of more than ~9 000 points); negative spc_status on bad
+ * extents. */
 int64_t spc_vnudge_workspace_bytes(int64_t n_cols, int32_t itot, int32_t jtot, int32_t ktot);
 
 #ifdef __cplusplus

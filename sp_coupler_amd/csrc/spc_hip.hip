@@ -9,6 +9,7 @@
 //   K3 k_backward  LES slab means -> GCM tendencies, masked above the LES top
 //   K4 k_backward_cons  the same with conservative (rho-weighted layer-mean) coarsening
 //   K5 k_diag      spifs.nc diagnostics
+//   K6 k_vnudge_*  variability nudge (qt_forcing == 'variance'): spc_vnudge.hpp, spc_vnudge2.hpp
 // The path is 1-D interpolation over short columns: HBM-bound, no MFMA.  Design:
 // a 256-thread workgroup owns CB consecutive columns; the source profiles of those columns are
 // loaded with flat, fully coalesced accesses over the contiguous [CB x n_lev] slab, converted and
@@ -1188,11 +1189,22 @@ template <typename T> KBwd<T> bwd_kernel(int geo, int wt, int blk, int pre)
 #undef SPC_BWD_ROW
 #undef SPC_BWD_ROW_BIG
 
-template <typename T> KBwd<T> cons_kernel(int geo)
+// K4 of a geometry; run-time geometry (geo 0): numpy's pairwise recursion unrolled to the depth nL needs (spc_k4.hpp) --
+// pd = 1, 2, 3 for LES grids of up to 256 / 512 / 1024 levels, else the explicit-stack form
+template <typename T> KBwd<T> cons_kernel(int geo, int pd)
 {
-    static const KBwd<T> kc[4] = {k_backward_cons2<T, 0, 0>, k_backward_cons2<T, 91, 160>, k_backward_cons2<T, 137, 512>,
+    static const KBwd<T> kc[4] = {k_backward_cons2<T, 0, 0, -1>, k_backward_cons2<T, 91, 160>, k_backward_cons2<T, 137, 512>,
                                   k_backward_cons2<T, 19, 160>};
-    return kc[geo];
+    static const KBwd<T> kd[3] = {k_backward_cons2<T, 0, 0, 1>, k_backward_cons2<T, 0, 0, 2>, k_backward_cons2<T, 0, 0, 3>};
+    return (geo == 0 && pd >= 1 && pd <= 3) ? kd[pd - 1] : kc[geo];
+}
+
+// depth of numpy's pairwise recursion over at most nL elements (<= 8192: one chunk); -1: use the explicit stack
+int cons_depth(int nL)
+{
+    if (nL > 1024) return -1;
+    const int d = vn_pw_depth(nL);
+    return d < 1 ? 1 : (d <= 3 ? d : -1);
 }
 
 template <typename T> int choose_bwd(const spc_dims *d, bool cons, Choice *c)
@@ -1205,7 +1217,7 @@ template <typename T> int choose_bwd(const spc_dims *d, bool cons, Choice *c)
     // PRE = false (8 waves per SIMD) pays between one round of workgroups and saturation: 1 025 ... 25 000 columns
     c->pre = (cons || sb || (pre_env >= 0 ? pre_env != 0 : (d->n_cols <= 1024 || d->n_cols > 25000))) ? 1 : 0;
     c->blk = sb ? BLOCK * sb : BLOCK;
-    c->cb = sb ? sb : (cons ? pick_cb(d, 4, false, sizeof(T), cons_kernel<T>(c->geo))
+    c->cb = sb ? sb : (cons ? pick_cb(d, 4, false, sizeof(T), cons_kernel<T>(c->geo, cons_depth(d->nL)))
                             : pick_cb(d, 1, false, sizeof(T), bwd_kernel<T>(c->geo, 0, BLOCK, c->pre)));
     size_t per_col, fixed;
     lds_elems(d, cons ? 4 : 1, false, &per_col, &fixed);
@@ -1235,7 +1247,7 @@ template <typename T> int backward_impl(const spc_dims *d, const spc_backward_ar
     }
     Choice c;
     if ((rc = choose_bwd<T>(d, cons, &c))) return rc;
-    const KBwd<T> kern = cons ? cons_kernel<T>(c.geo) : bwd_kernel<T>(c.geo, c.wt, c.blk, c.pre);
+    const KBwd<T> kern = cons ? cons_kernel<T>(c.geo, cons_depth(d->nL)) : bwd_kernel<T>(c.geo, c.wt, c.blk, c.pre);
     if (!kern) return fail(SPC_ERR_UNSUPPORTED, "%sbackward: no kernel instantiated for this launch choice (internal)");
     if ((rc = ensure_lds(kern, c.smem, cons ? "backward (conservative)" : "backward"))) return rc;
     BwdP<T> p;
@@ -1366,22 +1378,21 @@ static size_t vn_lds_need(int nij, int nleaf_max, int t)
 }
 
 // Planes that fit the LDS (KT levels x nij x 16 B <= 150 KiB, KT a power of two <= 16; 64 x 64 planes: KT = 2) are
-// solved there; larger planes (> ~9 000 points) keep the sweeping kernel.  SPC_VN_LDS=0: A/B.  Returns whether the LDS
-// path applies and, if so, the levels per workgroup and the leaf count of numpy's pairwise tree.
+// solved there; larger planes (> ~9 000 points) are streamed from the transposed workspace.  Returns whether the LDS
+// path applies, the levels per workgroup and the leaf count of numpy's pairwise tree.
 static bool vn_lds_fit(int nij, int *kt_, int *log2_kt_, int *nleaf_max_)
 {
     int kt = 16, log2_kt = 4;
     const int cn = nij < 8192 ? nij : 8192, nleaf_max = nij > 8192 ? VN_MAXLEAF : vn_count_leaves(cn);
     while (kt > 1 && vn_lds_need(nij, nleaf_max, kt) > (size_t)VN2_MAX_LDS) { kt >>= 1; --log2_kt; }
     *kt_ = kt; *log2_kt_ = log2_kt; *nleaf_max_ = nleaf_max;
-    return vn_lds_need(nij, nleaf_max, kt) <= (size_t)VN2_MAX_LDS && env_int("SPC_VN_LDS", 1);
+    return vn_lds_need(nij, nleaf_max, kt) <= (size_t)VN2_MAX_LDS;
 }
 
 int64_t spc_vnudge_workspace_bytes(int64_t n_cols, int32_t itot, int32_t jtot, int32_t ktot)
 {
     if (n_cols < 0 || itot < 1 || jtot < 1 || ktot < 1 || (int64_t)itot * jtot > INT32_MAX / 2)
         return fail(SPC_ERR_INVALID_ARGUMENT, "%svariability_nudge: bad extents");
-    if (!env_int("SPC_VN_LDS", 1) || !env_int("SPC_VN_TRANSPOSE", 1)) return 0;     // the sweeping kernel uses no workspace
     return n_cols * 2 * (int64_t)itot * jtot * ktot * 8;
 }
 
@@ -1402,18 +1413,18 @@ int spc_variability_nudge_f64(const spc_vnudge_args *a, void *stream)
     p.presf = (const double *)a->presf; p.ql_ref = (const double *)a->ql_ref; p.ql = (const double *)a->ql;
     p.qt = (double *)a->qt; p.thl = (double *)a->thl; p.beta = (double *)a->beta; p.a_add = (double *)a->a_add;
     p.qt_std = (double *)a->qt_std; p.status = a->status;
-    // Planes that fit the LDS (KT levels x nij x 16 B <= 150 KiB, KT a power of two <= 16; 64 x 64 planes: KT = 2)
-    // are solved there (spc_vnudge2.hpp); larger planes (> ~9 000 points) keep the sweeping kernel.  SPC_VN_LDS=0: A/B.
     // Where the planes live while the root finder runs: in the CU's LDS when KT levels' planes fit (KT x nij x 16 B <= 150
     // KiB: up to ~9 000 points; 64 x 64 planes: KT = 2), else -- 128 x 128 and up -- in the caller's transposed workspace,
-    // one workgroup per level streaming its contiguous planes (k_vnudge_solve<true>).  Without a workspace large planes keep
-    // the sweeping kernel k_vnudge.  SPC_VN_LDS=0 forces the latter (A/B, tests).
+    // one workgroup per level streaming its contiguous planes (k_vnudge_solve<true>; SPC_VN_GLOBAL=1 forces it: A/B, tests).
     int kt, log2_kt, nleaf_max;
-    const bool lds = vn_lds_fit(p.nij, &kt, &log2_kt, &nleaf_max);
+    const bool fits = vn_lds_fit(p.nij, &kt, &log2_kt, &nleaf_max);
     const int64_t work_need = a->n_cols * 2 * (int64_t)p.nij * a->ktot * 8;
     const bool have_work = a->work && a->work_bytes >= work_need && env_int("SPC_VN_TRANSPOSE", 1);
-    const bool global = !lds && have_work && env_int("SPC_VN_LDS", 1) && env_int("SPC_VN_GLOBAL", 1);
-    if (lds || global) {
+    const bool global = have_work && (!fits || env_int("SPC_VN_GLOBAL", 0));
+    if (!fits && !have_work)
+        return fail(SPC_ERR_INVALID_ARGUMENT, "%svariability_nudge: planes of %lld points do not fit the LDS: `work` of "
+                    "spc_vnudge_workspace_bytes() bytes is required", "", (long long)p.nij);
+    {
         auto lds_need = [&](int t) { return global ? (size_t)t * nleaf_max * 8 + VN2_THREADS * 12 : vn_lds_need(p.nij, nleaf_max, t); };
         // many workgroups (more than two rounds of one per CU): half the levels and half the threads per workgroup where
         // that lets TWO workgroups share a CU's LDS -- one's barriers and serial steps overlap the other's sums
@@ -1473,8 +1484,6 @@ int spc_variability_nudge_f64(const spc_vnudge_args *a, void *stream)
         }
         return launch_status("k_vnudge_std");
     }
-    hipLaunchKernelGGL(k_vnudge, dim3((unsigned)((a->ktot + VN_KT - 1) / VN_KT), (unsigned)a->n_cols), dim3(64 * VN_WAVES), 0, (hipStream_t)stream, p);
-    return launch_status("k_vnudge");
 }
 
 int spc_abi_version(void) { return SPC_ABI_VERSION; }
@@ -1507,7 +1516,10 @@ int spc_describe_launch(const spc_dims *d, int pass, int flags, int elem_size, c
     else if (pass == 1)
         snprintf(name, sizeof(name), "k_backward<%s,%d,%d,wt=%d,blk=%d,pre=%d>", ty, GEO_NG[c.geo], GEO_NL[c.geo], c.wt, c.blk, c.pre);
     else if (pass == 4)
-        snprintf(name, sizeof(name), "k_backward_cons2<%s,%d,%d>", ty, GEO_NG[c.geo], GEO_NL[c.geo]);
+        if (c.geo == 0)
+            snprintf(name, sizeof(name), "k_backward_cons2<%s,0,0,pd=%d>", ty, cons_depth(d->nL));
+        else
+            snprintf(name, sizeof(name), "k_backward_cons2<%s,%d,%d>", ty, GEO_NG[c.geo], GEO_NL[c.geo]);
     else
         snprintf(name, sizeof(name), "%s<%s>", c.kernel, ty);
     return snprintf(buf, (size_t)buflen, "%s cb=%d grid=%u block=%d lds=%lld", name, c.cb, c.grid, c.blk, (long long)c.smem);

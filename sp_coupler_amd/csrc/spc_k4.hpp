@@ -31,7 +31,10 @@ template <int D, typename F> __device__ __forceinline__ auto vn_pw(const F &term
 
 // NG / NL != 0: level counts fixed at compile time and contiguous columns (as k_forward / k_backward): the flat-index
 // divisions become multiply-shifts.
-template <typename T, int NG = 0, int NL = 0> __global__ __launch_bounds__(BLOCK) void k_backward_cons2(const BwdP<T> p)
+// PD (run-time geometry only): numpy's recursion unrolled to PD levels, enough for every layer of <= nL cells when
+// PD >= vn_pw_depth(nL) -- the host picks the instantiation (1, 2, 3: nL up to 256 / 512 / 1024 cells); PD = -1 keeps
+// the explicit stack of vn_npsum for taller LES grids (152 VGPRs, scratch memory, 3 waves per SIMD).
+template <typename T, int NG = 0, int NL = 0, int PD = -1> __global__ __launch_bounds__(BLOCK) void k_backward_cons2(const BwdP<T> p)
 {
     const DimsP &d = p.d;
     const int nG = NG ? NG : d.nG, nL = NL ? NL : d.nL, cb = d.cb, tid = threadIdx.x, nLp = nL + 1;
@@ -132,6 +135,7 @@ template <typename T, int NG = 0, int NL = 0> __global__ __launch_bounds__(BLOCK
             };
             T S;
             if constexpr (NL != 0) S = T(0) + vn_pw<vn_pw_depth(NL)>(term, 0, cnt);         // cnt <= NL <= 8192: one chunk
+            else if constexpr (PD >= 0) S = T(0) + vn_pw<PD>(term, 0, cnt);                 // cnt <= nL, depth checked by the host
             else S = cnt <= 128 ? T(0) + vn_leaf(term, 0, cnt) : vn_npsum(term, cnt);
             const T ea = wsum ? w[ia] * da : (w[ia] * q(ia)) * da;                     // Sa / Swa, sputils.py:154,159
             const T eb = wsum ? w[ib] * db : (w[ib] * q(ib)) * db;                     // Sb / Swb

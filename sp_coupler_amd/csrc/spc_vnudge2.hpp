@@ -1,17 +1,17 @@
-// spc_vnudge2.hpp -- variability nudge with the planes resident in LDS (K6a solve + K6b apply / std).
+// spc_vnudge2.hpp -- the kernels of the variability nudge (K6): transpose, solve, update, std.
 //
-// k_vnudge (spc_vnudge.hpp) re-reads a level's qt / qsat plane from memory for every evaluation of the root finder
-// (~30 sweeps per level: L2-resident for a few LES, HBM-bound for hundreds).  Here a workgroup owns KT levels of one
-// column, KT chosen so that their qt and qsat planes (KT x nij x 16 B) FIT THE CU's LDS (64 x 64 planes: KT = 2,
-// 128 KiB); it loads them once and runs every evaluation from LDS.  The 512 threads split into KT groups, one per level;
-// inside a group 8 consecutive lanes carry the 8 accumulators of ONE numpy pairwise leaf (<= 128 elements; lane j sums
-// elements j, j+8, ...) and combine them ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) by shuffles -- the order numpy uses -- so a
-// 4096-point plane is summed by 256 threads in 16 steps; the leaf sums are then combined in numpy's tree order by
-// dependency rounds (vn_build_rounds).  Root finder, branches and status bits are those of k_vnudge (scipy brentq
-// restated as a resumable step function, one evaluation per level and round).  The solve leaves beta / a and the
-// apply code in `status`; k_vnudge_apply (16 levels of one column per workgroup, coalesced rows streamed through an LDS
-// tile) then rewrites qt (thl with constantT) and takes qt.std(axis=(0,1)) in numpy's sequential order.
-// Bit-identical to k_vnudge and to the NumPy / SciPy oracle (tests/test_vnudge.py runs both paths).
+// A sweep of a level's qt / qsat plane per evaluation of the root finder (~30 per level) is what the reference does and
+// what round 1's kernel did from memory.  Here a workgroup owns KT levels of one column, KT chosen so that their qt and
+// qsat planes (KT x nij x 16 B) FIT THE CU's LDS (64 x 64 planes: KT = 2, 128 KiB); it loads them once -- coalesced, from
+// contiguous planes k_vnudge_transpose wrote into the caller's workspace -- and runs every evaluation from LDS.  The 512
+// threads split into KT groups, one per level; inside a group 8 consecutive lanes carry the 8 accumulators of ONE numpy
+// pairwise leaf (<= 128 elements; lane j sums elements j, j+8, ...) and combine them ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))
+// by shuffles -- the order numpy uses -- so a 4096-point plane is summed by 256 threads in 16 steps; the leaf sums are
+// then combined in numpy's tree order by dependency rounds (vn_build_rounds).  scipy's brentq runs as a resumable step
+// function, one evaluation per level and round.  Planes too large for the LDS (128 x 128 and up) are streamed from the
+// workspace instead, one workgroup per level (k_vnudge_solve<true>).  The solve leaves beta / a and the apply code in
+// `status`; k_vnudge_update rewrites qt (thl with constantT) elementwise and k_vnudge_std takes qt.std(axis=(0,1)) in
+// numpy's sequential order.  Bit-identical to the NumPy / SciPy oracle on every path (tests/test_vnudge.py).
 #pragma once
 
 constexpr int VN2_THREADS = 512;
@@ -87,7 +87,7 @@ __host__ __device__ inline int vn_build_rounds(int nleaf, const unsigned short *
 // (planes of up to ~9 000 points).  GLOBAL = true: planes too large for the LDS (128 x 128 and up -- ordinary DALES sizes)
 // stay in the caller's transposed workspace, contiguous per level, and every evaluation streams them from L2 / the
 // Infinity Cache with coalesced 64-B-per-leaf-group reads: one workgroup per level (KT = 1), i.e. n_cols x ktot workgroups
-// instead of the sweeping kernel's n_cols x ktot / 16, and no strided [ij][k] access.  Same sums, same order, same bits.
+// and no strided [ij][k] access.  Same sums, same order, same bits as the LDS form.
 template <bool GLOBAL> __global__ __launch_bounds__(VN2_THREADS) void k_vnudge_solve(const Vn2P q)
 {
     const VnP &p = q.p;

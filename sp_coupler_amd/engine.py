@@ -434,18 +434,15 @@ class Engine:
         res["status"] = self.empty(n, ktot, dtype=torch.int32)
         a.beta, a.a_add, a.qt_std, a.status = (res["beta"].data_ptr(), res["a"].data_ptr(), res["qt_std"].data_ptr(),
                                                res["status"].data_ptr())
-        # scratch for the transposed qt / qsat planes (include/spc.h: spc_vnudge_args.work), kept between calls; the
-        # library says how much it wants: nothing when the planes are too large for its LDS path
+        # scratch for the transposed qt / qsat planes (include/spc.h: spc_vnudge_args.work), kept between calls and sized
+        # by the library
         need = int(self.lib.spc_vnudge_workspace_bytes(n, itot, jtot, ktot))
         if need < 0:
             _abi.check(self.lib, need)
-        if need == 0:
-            self._vn_work = None
-        elif self._vn_work is None or self._vn_work.numel() < need:
+        if self._vn_work is None or self._vn_work.numel() < need:
             self._vn_work = None
             self._vn_work = torch.empty(need, dtype=torch.uint8, device=self.device)
-        if self._vn_work is not None:
-            a.work, a.work_bytes = self._vn_work.data_ptr(), self._vn_work.numel()
+        a.work, a.work_bytes = self._vn_work.data_ptr(), self._vn_work.numel()
         with torch.cuda.device(self.device):
             rc = self.lib.spc_variability_nudge_f64(ctypes.byref(a), _stream_ptr(stream, self.device))
         _abi.check(self.lib, rc)

@@ -268,11 +268,17 @@ def test_conservative_coarsening_bit_exact(eng, n, nG, nL, per_col):
     assert (host(got["f_T"]) != 0).any()
 
 
-def test_conservative_coarsening_thick_layers_recursive_pairwise_sums(eng):
-    """GCM layers that span hundreds of LES cells (1 m LES spacing): ndarray.sum() then recurses (blocks of 128, halves
-    split at multiples of 8); the kernel's sums must follow.  Round 1 refused nL > 513; any nL that fits LDS works now."""
-    gcm, zf, zh, prof = synthetic.make_batch(12, 91, 2000, seed=52)
-    zf, zh = numpy.ascontiguousarray(zf * 0.1), numpy.ascontiguousarray(zh * 0.1)          # 1 m cells, top at 2 km
+@pytest.mark.parametrize("nL,scale,pd", [(2000, 0.1, -1), (250, 0.01, 1), (500, 0.01, 2), (1000, 0.01, 3)])
+def test_conservative_coarsening_thick_layers_recursive_pairwise_sums(eng, nL, scale, pd):
+    """GCM layers that span hundreds of LES cells (1 m / 0.1 m LES spacing): ndarray.sum() then recurses (blocks of 128,
+    halves split at multiples of 8); the kernel's sums must follow.  Round 1 refused nL > 513; any nL that fits LDS works
+    now.  The run-time-geometry K4 unrolls numpy's recursion to the depth nL needs (pd = 1, 2, 3: up to 256 / 512 / 1024
+    LES levels; taller grids walk it with an explicit stack, pd = -1): every one of the four instantiations is run."""
+    from sp_coupler_amd import _abi
+    gcm, zf, zh, prof = synthetic.make_batch(12, 91, nL, seed=52)
+    zf, zh = numpy.ascontiguousarray(zf * scale), numpy.ascontiguousarray(zh * scale)          # 1 m cells, top at 2 km
+    d = _abi.Dims(12, 91, nL, 91, 92, nL, 1, 0)
+    assert _abi.describe_launch(eng.lib, d, 4, 0).startswith("k_backward_cons2<f64,0,0,pd=%d>" % pd)
     g, p = to_dev(gcm, eng.device), to_dev(prof, eng.device)
     zf_d, zh_d = torch.from_numpy(zf).to(eng.device), torch.from_numpy(zh).to(eng.device)
     got = eng.backward(g, zf_d, p, FACTOR, DT, Zf=None, conservative=True, zh=zh_d)
@@ -280,7 +286,7 @@ def test_conservative_coarsening_thick_layers_recursive_pairwise_sums(eng):
     ref_f = oracle_c.forward(gcm, zf, zh, prof, FACTOR, DT)
     ref = oracle_c.backward(gcm, ref_f["Zf"], zf, prof, FACTOR, DT, conservative=True, zh=zh, Zh=ref_f["Zh"])
     cells = numpy.diff(numpy.searchsorted(zh, ref_f["Zh"][0][::-1]))
-    assert cells.max() > 150                                 # the fixture really has layers of > 128 cells
+    assert cells.max() > 128                                 # the fixture really has layers of > 128 cells
     check_backward({k: host(v) for k, v in got.items()}, ref)
     # and against NumPy itself (the reference's own evaluation) on a few columns
     sub = {k: v[:3] for k, v in gcm.items()}

@@ -131,27 +131,29 @@ class FieldLES:
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lds", ["1", "pair", "strided", "0"])
+@pytest.mark.parametrize("lds", ["1", "pair", "strided", "global"])
 @pytest.mark.parametrize("constantT", [False, True])
 def test_kernel_matches_the_numpy_scipy_oracle(constantT, lds, monkeypatch):
-    """K6 through the drop-in API against the oracle, every device path -- planes resident in LDS (csrc/spc_vnudge2.hpp,
-    the default where the planes fit: 512-thread workgroups, paired 256-thread workgroups as for many LES, and loading
-    without the transposed workspace) and the sweeping kernel (csrc/spc_vnudge.hpp) -- on synthetic LES:
-    two small planes with odd extents (leaf tails of the pairwise sum; 16 levels per workgroup), 32 x 32 (8 levels per
-    workgroup), 64 x 32 (4), 64 x 64 x 160, the bundled DALES case (2), 90 x 90 (1), and 96 x 96 planes (more than one
-    8192-element chunk; too large for the LDS: the sweeping kernel either way): beta, a, the updated qt and qt_std
-    BIT-exact, status equal; thl (constantT) within 8 ulp."""
+    """K6 through the drop-in API against the oracle, every device path -- planes resident in LDS (the default where they
+    fit: 512-thread workgroups; "pair": paired 256-thread workgroups as for many LES; "strided": loaded without the
+    transposed workspace) and planes streamed from the workspace by one workgroup per level (the default for large planes;
+    "global": at every size) -- on synthetic LES: two small planes with odd extents (leaf tails of the pairwise sum; 16
+    levels per workgroup), 32 x 32 (8 levels per workgroup), 64 x 32 (4), 64 x 64 x 160, the bundled DALES case (2),
+    90 x 90 (1), 92 x 92 (two 8192-element chunks in LDS), 96 x 96, 128 x 128, 200 x 170 (too large for the LDS): beta, a,
+    the updated qt and qt_std BIT-exact, status equal; thl (constantT) within 8 ulp."""
     from sp_coupler_amd import spcpl
     spcpl.set_engine(None)
-    monkeypatch.setenv("SPC_VN_LDS", "0" if lds == "0" else "1")
+    monkeypatch.setenv("SPC_VN_GLOBAL", "1" if lds == "global" else "0")        # planes streamed from the workspace at EVERY size
     monkeypatch.setenv("SPC_VN_PAIR", "2" if lds == "pair" else "1")            # two 256-thread workgroups per CU
     monkeypatch.setenv("SPC_VN_TRANSPOSE", "0" if lds == "strided" else "1")    # without the transposed workspace
     shapes = [(16, 12, 40, 3), (9, 7, 23, 4), (64, 64, 160, 5), (96, 96, 12, 6), (32, 32, 24, 7), (64, 32, 21, 8), (90, 90, 12, 10),
               (92, 92, 12, 11), (128, 128, 12, 12), (200, 170, 5, 13)]
     # 92 x 92 = 8464 points: the LDS path with TWO chunks of numpy's 8192-element blocking; 96 x 96, 128 x 128 and 200 x 170
-    # (4 chunks + a ragged last one) do not fit the LDS: with the transposed workspace one workgroup per level streams the
-    # planes (k_vnudge_solve<true>), without it ("strided", "0") the sweeping kernel k_vnudge takes them
+    # (4 chunks + a ragged last one) do not fit the LDS: one workgroup per level streams the planes from the transposed
+    # workspace (k_vnudge_solve<true>; "global" runs EVERY shape that way); without a workspace ("strided") they are refused
     for group in ([0, 1], [2], [3], [4], [5], [6], [7], [8], [9]):     # one launch per extent (a launch has one plane geometry)
+        if lds == "strided" and shapes[group[0]][0] * shapes[group[0]][1] > 9000:
+            continue
         fs = [make_les_fields(*shapes[g][:3], seed=shapes[g][3]) for g in group]
         if len(group) == 2:                             # same geometry needed inside one launch: pad the second to the first
             fs[1] = make_les_fields(*shapes[group[0]][:3], seed=shapes[group[1]][3])

@@ -1190,7 +1190,7 @@ template <typename T> KBwd<T> bwd_kernel(int geo, int wt, int blk, int pre)
 #undef SPC_BWD_ROW_BIG
 
 // K4 of a geometry; run-time geometry (geo 0): numpy's pairwise recursion unrolled to the depth nL needs (spc_k4.hpp) --
-// pd = 1, 2, 3 for LES grids of up to 256 / 512 / 1024 levels, else the explicit-stack form
+// pd = 1, 2, 3 for LES grids of up to 248 / 488 / 968 levels, else the explicit-stack form
 template <typename T> KBwd<T> cons_kernel(int geo, int pd)
 {
     static const KBwd<T> kc[4] = {k_backward_cons2<T, 0, 0, -1>, k_backward_cons2<T, 91, 160>, k_backward_cons2<T, 137, 512>,

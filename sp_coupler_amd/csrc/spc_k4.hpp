@@ -32,7 +32,7 @@ template <int D, typename F> __device__ __forceinline__ auto vn_pw(const F &term
 // NG / NL != 0: level counts fixed at compile time and contiguous columns (as k_forward / k_backward): the flat-index
 // divisions become multiply-shifts.
 // PD (run-time geometry only): numpy's recursion unrolled to PD levels, enough for every layer of <= nL cells when
-// PD >= vn_pw_depth(nL) -- the host picks the instantiation (1, 2, 3: nL up to 256 / 512 / 1024 cells); PD = -1 keeps
+// PD >= vn_pw_depth(nL) -- the host picks the instantiation (1, 2, 3: nL up to 248 / 488 / 968 cells); PD = -1 keeps
 // the explicit stack of vn_npsum for taller LES grids (152 VGPRs, scratch memory, 3 waves per SIMD).
 template <typename T, int NG = 0, int NL = 0, int PD = -1> __global__ __launch_bounds__(BLOCK) void k_backward_cons2(const BwdP<T> p)
 {

@@ -268,11 +268,11 @@ def test_conservative_coarsening_bit_exact(eng, n, nG, nL, per_col):
     assert (host(got["f_T"]) != 0).any()
 
 
-@pytest.mark.parametrize("nL,scale,pd", [(2000, 0.1, -1), (250, 0.01, 1), (500, 0.01, 2), (1000, 0.01, 3)])
+@pytest.mark.parametrize("nL,scale,pd", [(2000, 0.1, -1), (240, 0.01, 1), (480, 0.004, 2), (960, 0.002, 3)])
 def test_conservative_coarsening_thick_layers_recursive_pairwise_sums(eng, nL, scale, pd):
     """GCM layers that span hundreds of LES cells (1 m / 0.1 m LES spacing): ndarray.sum() then recurses (blocks of 128,
     halves split at multiples of 8); the kernel's sums must follow.  Round 1 refused nL > 513; any nL that fits LDS works
-    now.  The run-time-geometry K4 unrolls numpy's recursion to the depth nL needs (pd = 1, 2, 3: up to 256 / 512 / 1024
+    now.  The run-time-geometry K4 unrolls numpy's recursion to the depth nL needs (pd = 1, 2, 3: up to 248 / 488 / 968
     LES levels; taller grids walk it with an explicit stack, pd = -1): every one of the four instantiations is run."""
     from sp_coupler_amd import _abi
     gcm, zf, zh, prof = synthetic.make_batch(12, 91, nL, seed=52)

@@ -20,7 +20,9 @@ if has bench; then
 fi
 if has prof; then
   cd /tmp
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 200 --warmup 20 --cpu-seconds 0 > $R/gpurun_out/prof_$TAG.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 200 --warmup 20 --cpu-seconds 0 --no-anchor > $R/gpurun_out/prof_$TAG.log 2>&1
+  # (--no-anchor: `--stats` averages per kernel NAME and the anchor launches the same K1 / K3 instantiation on 10x the columns;
+  #  tools/trace_by_grid.py splits a full run's trace by grid size instead)
   echo "rocprof stats exit=$?"
   cd $R
 fi

@@ -1065,11 +1065,13 @@ template <typename T> KLean<T> fwd_lean_kernel(int geo, int wt, int blk, int pre
     return blk == 512 ? k512[geo] : (blk == 1024 ? k1024[geo] : nullptr);
 }
 
-template <typename T> KFull<T> fwd_full_kernel(int geo, int wt, int pre)
+// the FULL variant (optional outputs, surface coupling: convert_profiles() and cplsurf=True, off the default path of
+// splib.py:67) exists with plain stores only: write-through is worth ~5 % on launches of <= 4 k columns and would double
+// the number of its instantiations
+template <typename T> KFull<T> fwd_full_kernel(int geo, int pre)
 {
-    static const KFull<T> k[2][2][4] = {{SPC_FWD_ROW(true, 0, BLOCK, false), SPC_FWD_ROW(true, 1, BLOCK, false)},
-                                        {SPC_FWD_ROW(true, 0, BLOCK, true), SPC_FWD_ROW(true, 1, BLOCK, true)}};
-    return k[pre][wt][geo];
+    static const KFull<T> k[2][4] = {SPC_FWD_ROW(true, 0, BLOCK, false), SPC_FWD_ROW(true, 0, BLOCK, true)};
+    return k[pre][geo];
 }
 #undef SPC_FWD_ROW
 #undef SPC_FWD_ROW_BIG
@@ -1078,7 +1080,7 @@ template <typename T> int choose_fwd(const spc_dims *d, bool with_idx, bool full
 {
     c->kernel = "k_forward"; c->elem = (int)sizeof(T); c->full = full; c->idx = with_idx;
     c->geo = geometry_id(d);
-    c->wt = small_batch(d->n_cols * (int64_t)((6 * d->nL + 1) * sizeof(T) + (with_idx ? d->nG * 4 : 0)));
+    c->wt = full ? 0 : small_batch(d->n_cols * (int64_t)((6 * d->nL + 1) * sizeof(T) + (with_idx ? d->nG * 4 : 0)));
     // (137 <-> 512 never qualifies for small_block: 649 work items per column; nor does a launch whose write-through
     //  stores were switched off for an A/B run)
     const int sb = (full || !c->wt) ? 0 : small_block(d, d->nL + (with_idx ? d->nG : 0));
@@ -1087,7 +1089,7 @@ template <typename T> int choose_fwd(const spc_dims *d, bool with_idx, bool full
     c->pre = (sb || (pre_env >= 0 ? pre_env != 0 : d->n_cols <= 1024)) ? 1 : 0;   // measured: PRE = false wins from 1100 columns
     c->blk = sb ? BLOCK * sb : BLOCK;
     if (full)
-        c->cb = pick_cb(d, 0, with_idx, sizeof(T), fwd_full_kernel<T>(c->geo, 0, c->pre));
+        c->cb = pick_cb(d, 0, with_idx, sizeof(T), fwd_full_kernel<T>(c->geo, c->pre));
     else
         c->cb = sb ? sb : pick_cb(d, 0, with_idx, sizeof(T), fwd_lean_kernel<T>(c->geo, 0, BLOCK, c->pre));
     size_t per_col, fixed;
@@ -1134,7 +1136,7 @@ template <typename T> int forward_impl(const spc_dims *d, const spc_forward_args
         OP(f_u); OP(f_v); OP(f_thl); OP(f_qt); OP(f_ql); OP(ql_ref); OP(f_ps); p.idx = a->idx;
     };
     if (full) {
-        const KFull<T> kern = fwd_full_kernel<T>(c.geo, c.wt, c.pre);
+        const KFull<T> kern = fwd_full_kernel<T>(c.geo, c.pre);
         FwdP<T, true> p;
         fill(p);
         COP(rain); COP(rain_last); OOP(u); OOP(v); OOP(thl); OOP(qt); OOP(ps); OOP(Zf); OOP(Zh); OOP(rainrate);
@@ -1195,8 +1197,11 @@ template <typename T> KBwd<T> cons_kernel(int geo, int pd)
 {
     static const KBwd<T> kc[4] = {k_backward_cons2<T, 0, 0, -1>, k_backward_cons2<T, 91, 160>, k_backward_cons2<T, 137, 512>,
                                   k_backward_cons2<T, 19, 160>};
-    static const KBwd<T> kd[3] = {k_backward_cons2<T, 0, 0, 1>, k_backward_cons2<T, 0, 0, 2>, k_backward_cons2<T, 0, 0, 3>};
-    return (geo == 0 && pd >= 1 && pd <= 3) ? kd[pd - 1] : kc[geo];
+    if constexpr (std::is_same<T, double>::value) {      // (the float twin, config 5's tolerance sweep, keeps the stack form)
+        static const KBwd<T> kd[3] = {k_backward_cons2<T, 0, 0, 1>, k_backward_cons2<T, 0, 0, 2>, k_backward_cons2<T, 0, 0, 3>};
+        if (geo == 0 && pd >= 1 && pd <= 3) return kd[pd - 1];
+    }
+    return kc[geo];
 }
 
 // depth of numpy's pairwise recursion over at most nL elements (<= 8192: one chunk); -1: use the explicit stack
@@ -1517,7 +1522,7 @@ int spc_describe_launch(const spc_dims *d, int pass, int flags, int elem_size, c
         snprintf(name, sizeof(name), "k_backward<%s,%d,%d,wt=%d,blk=%d,pre=%d>", ty, GEO_NG[c.geo], GEO_NL[c.geo], c.wt, c.blk, c.pre);
     else if (pass == 4)
         if (c.geo == 0)
-            snprintf(name, sizeof(name), "k_backward_cons2<%s,0,0,pd=%d>", ty, cons_depth(d->nL));
+            snprintf(name, sizeof(name), "k_backward_cons2<%s,0,0,pd=%d>", ty, elem_size == 8 ? cons_depth(d->nL) : -1);
         else
             snprintf(name, sizeof(name), "k_backward_cons2<%s,%d,%d>", ty, GEO_NG[c.geo], GEO_NL[c.geo]);
     else

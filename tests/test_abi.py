@@ -110,8 +110,10 @@ def test_describe_launch_names_the_instantiation_the_launcher_would_pick(lib):
     assert k3(25001) == "k_backward<f64,91,160,wt=0,blk=256,pre=1>"
     assert k3(4096, nG=19) == "k_backward<f64,19,160,wt=1,blk=256,pre=0>"
     full = _abi.describe_launch(lib, d(4096), 0, 3)
-    assert full.startswith("k_forward<f64,full,91,160,wt=1,blk=256,pre=0> cb=")
+    assert full.startswith("k_forward<f64,full,91,160,wt=0,blk=256,pre=0> cb=")        # FULL: plain stores only
     assert _abi.describe_launch(lib, d(4096), 4, 0).startswith("k_backward_cons2<f64,91,160> cb=")
+    assert _abi.describe_launch(lib, d(4096, nL=400), 4, 0).startswith("k_backward_cons2<f64,0,0,pd=2> cb=")
+    assert _abi.describe_launch(lib, d(4096, nL=2000), 4, 0).startswith("k_backward_cons2<f64,0,0,pd=-1> cb=")
     assert _abi.describe_launch(lib, d(4096), 0, 1, 4).startswith("k_forward<f32,lean,91,160,")
     txt = _abi.describe_launch(lib, d(35718), 0, 1)
     fields = dict(kv.split("=") for kv in txt.split()[1:])

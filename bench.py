@@ -260,6 +260,58 @@ def dropin_rate(eng, n_les=1024, steps=30, warmup=5, per_les_steps=5):
     return out
 
 
+def in_process_all_gpus(ids, factor, dt, args):
+    """config 4 (348 528 columns) through multi.MultiDeviceEngine: ONE process, the column batch in row blocks on every
+    listed device, one launch plan per device, launches issued device by device (what `spcpl.get_engine()` gives the
+    reference's single master process on a multi-GPU node).  Same step and byte model as the headline."""
+    import torch
+    from sp_coupler_amd import synthetic
+    from sp_coupler_amd.engine import Engine
+    from sp_coupler_amd.multi import MultiDeviceEngine, describe_partition
+    from sp_coupler_amd.transfer import Sharded
+    n, nG, nL, seed = synthetic.CONFIGS[4]
+    if args.cols:
+        n = args.cols
+    multi = MultiDeviceEngine([Engine("cuda:%d" % i) for i in ids], min_cols_per_device=1)
+    b = multi.bounds_for(n)
+    need = ("U", "V", "T", "SH", "QL", "QI", "Pfull", "Phalf", "A", "Zgfull", "Zghalf", "THL", "QT", "QL_ice", "PS")
+    parts_g, parts_p, zfs, zhs = [], [], [], []
+    for d, e in enumerate(multi.engines):           # each device generates its own rows in place (device-side tiling)
+        rows = max(b[d + 1] - b[d], 1)
+        g, zf_d, zh_d, p, _ = synthetic.make_batch_tiled_device(e.device, rows, nG, nL, seed=seed + 1000 * d,
+                                                                 couple_surface=False, keys=need)
+        cut = b[d + 1] - b[d]
+        parts_g.append({k: v[:cut] for k, v in g.items()})
+        parts_p.append({k: v[:cut] for k, v in p.items()})
+        zfs.append(zf_d)
+        zhs.append(zh_d)
+    gs = {k: Sharded([pg[k] for pg in parts_g], b) for k in parts_g[0]}
+    ps = {k: Sharded([pp[k] for pp in parts_p], b) for k in parts_p[0]}
+    fp, bp = multi.plan_exchange(gs, Sharded(zfs), Sharded(zhs), ps, factor, factor, dt, cols_per_block=args.cols_per_block)
+
+    def step():
+        fp.launch()
+        bp.launch()
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < HEAT_MS:
+        for _ in range(4):
+            step()
+        multi.synchronize()
+    steps = max(20, min(args.steps, 100))
+    for _ in range(max(args.warmup, 3)):
+        step()
+    multi.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    multi.synchronize()
+    el = time.perf_counter() - t0
+    return {"workload": "config 4: %d synthetic SP columns, ONE process, row blocks on %d device(s) (multi.MultiDeviceEngine)" % (n, len(ids)),
+            "devices": ["cuda:%d" % i for i in ids], "distinct_devices": len(set(ids)), "partition": describe_partition(multi, n),
+            "value": n * steps / el, "unit": "column-exchanges/s", "steps": steps, "ms_per_step": el / steps * 1e3,
+            "note": "no collective, no peer traffic; compare with scaling_anchor (one GPU) and the `--gpus N` lines (one rank per GPU)"}
+
+
 class Workload:
     """ROTATE batches of one configuration resident in HBM + the exchange plans bench.py times."""
 
@@ -374,6 +426,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="process-group backend for N>1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--device", type=int, default=None, help="force this HIP device for every rank (rehearsal on a 1-GPU box)")
     ap.add_argument("--no-anchor", action="store_true", help="skip the config-4-on-one-GPU `scaling_anchor` extra at N=1")
+    ap.add_argument("--multi-devices", default=None,
+                    help="N=1 extra `in_process_all_gpus`: config 4 through multi.MultiDeviceEngine on these device ids (default: every "
+                         "visible GPU when there is more than one; '0,0' rehearses the path with two engines on one GPU; 'none' skips)")
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="N>1 launch mechanics only (rendezvous, sharding, barrier, max-reduction over gloo; no GPU work): CPU tests")
     args = ap.parse_args()
@@ -550,6 +605,19 @@ def main():
         del w4
         torch.cuda.empty_cache()
 
+    inproc = None
+    ids = None
+    if world == 1 and args.multi_devices != "none" and not args.no_kernel_events:
+        if args.multi_devices:
+            ids = [int(x) for x in args.multi_devices.split(",")]
+        elif torch.cuda.device_count() > 1:
+            ids = list(range(torch.cuda.device_count()))
+    if ids:
+        try:
+            inproc = in_process_all_gpus(ids, factor, dt_gcm, args)
+        except Exception as e:                       # a reported extra, never fatal for the headline
+            inproc = {"error": repr(e)}
+
     dropin = None
     if world == 1 and not args.no_dropin:
         try:
@@ -616,6 +684,8 @@ def main():
         out["small_batch"] = small
     if anchor is not None:
         out["scaling_anchor"] = anchor
+    if inproc is not None:
+        out["in_process_all_gpus"] = inproc
     if dropin is not None:
         out["dropin"] = dropin
         out["dropin_value"] = dropin.get("batched_protocol", {}).get("value")

@@ -1478,6 +1478,7 @@ int spc_variability_nudge_f64(const spc_vnudge_args *a, void *stream)
                            (hipStream_t)stream, p);
         if ((rc = launch_status("k_vnudge_update"))) return rc;
         const dim3 sgrid((unsigned)((a->ktot + 15) / 16), (unsigned)a->n_cols);
+        p.pad = env_int("SPC_VN_STD_DEBUG", 0);
         if ((int64_t)sgrid.x * sgrid.y <= 256 && env_int("SPC_VN_STD_ROWS", 512) == 512) {
             const size_t ssmem = (size_t)2 * 512 * 16 * sizeof(double);
             if ((rc = ensure_lds(k_vnudge_std<512>, ssmem, "variability_nudge (std)"))) return rc;

@@ -416,6 +416,43 @@ __global__ __launch_bounds__(256) void k_vnudge_update(const VnP p)
 // kept ONE 128-row tile in flight per workgroup, its summing wave also loaded, and it was bound by the load latency of
 // each tile: 143 us for a 64 x 64 x 160 LES even when no level needed a nudge.)  ROWS = 512 (128 KiB of LDS, one
 // workgroup per CU) for few workgroups, 256 for many.
+// rows [0, nr) of one LDS tile added IN ORDER to `acc` (SQ: their squared deviations from `mean`): the reads of the next G
+// rows are in flight while the current G are added.  Separate instantiations for the two passes keep the loop body free of
+// selects and register copies.
+template <bool SQ, int ROWS> __device__ __forceinline__ double vs_sum_tile(const double (*tl)[16], int lane, int nr, double mean, double acc)
+{
+    constexpr int G = 16;
+    if (nr == ROWS) {
+        // a full tile: the whole tile unrolled, group g + 1 read from LDS while group g is added (no loop-carried registers,
+        // hence no copies between them); sched_barrier keeps the reads IN FRONT of the chain they overlap
+        double v[2][G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) v[0][i] = tl[i][lane];
+#pragma unroll
+        for (int g = 0; g < ROWS / G; ++g) {
+            if (g + 1 < ROWS / G) {
+#pragma unroll
+                for (int i = 0; i < G; ++i) v[(g + 1) & 1][i] = tl[(g + 1) * G + i][lane];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (SQ) {
+#pragma unroll
+                for (int i = 0; i < G; ++i) { const double dlt = v[g & 1][i] - mean; v[g & 1][i] = dlt * dlt; }
+            }
+#pragma unroll
+            for (int i = 0; i < G; ++i) acc += v[g & 1][i];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return acc;
+    }
+    for (int r0 = 0; r0 < nr; ++r0) {                         // the ragged last tile
+        const double x = tl[r0][lane];
+        if constexpr (SQ) { const double dlt = x - mean; acc += dlt * dlt; }
+        else acc += x;
+    }
+    return acc;
+}
+
 constexpr int VS_THREADS = 320;
 template <int ROWS> __global__ __launch_bounds__(VS_THREADS) void k_vnudge_std(const VnP p)
 {
@@ -435,19 +472,27 @@ template <int ROWS> __global__ __launch_bounds__(VS_THREADS) void k_vnudge_std(c
     const double *const qt = p.qt + base;
     const int ntile = (nij + ROWS - 1) / ROWS;
     double w[U];
+    const int dbg = p.pad;                               // experiments only (SPC_VN_STD_DEBUG): 1 no adds, 2 no loads
     auto load_tile = [&](int t) {                        // rows past the plane's end re-read its last row: never added
+        if (dbg & 2) return;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int ij = t * ROWS + row + 16 * u;
             w[u] = qt[(int64_t)(ij < nij ? ij : nij - 1) * ks];
         }
     };
-    auto store_tile = [&](int t) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) s_tile[t & 1][row + 16 * u][lane] = w[u];
-    };
     double mean = 0.0, acc = 0.0;
-    for (int pass = 0; pass < 2; ++pass) {               // pass 0: sum -> mean; pass 1: sum of squared deviations
+    int pass = 0;
+    auto store_tile = [&](int t) {                       // pass 1: the LOADER waves square the deviations, the adder only adds
+        if (pass == 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) s_tile[t & 1][row + 16 * u][lane] = w[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const double dlt = w[u] - mean; s_tile[t & 1][row + 16 * u][lane] = dlt * dlt; }
+        }
+    };
+    for (pass = 0; pass < 2; ++pass) {                   // pass 0: sum -> mean; pass 1: sum of squared deviations
         acc = 0.0;
         if (!adder) {
             load_tile(0);
@@ -457,39 +502,9 @@ template <int ROWS> __global__ __launch_bounds__(VS_THREADS) void k_vnudge_std(c
         __syncthreads();
         for (int t = 0; t < ntile; ++t) {
             if (adder) {
-                if (row == 0) {
+                if (row == 0 && !(dbg & 1)) {
                     const int nr = (nij - t * ROWS) < ROWS ? (nij - t * ROWS) : ROWS;
-                    const double (*const tl)[16] = s_tile[t & 1];
-                    double a[16], b[16];
-                    int r0 = 0;
-                    if (nr >= 16) {
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) a[i] = tl[i][lane];
-                    }
-                    for (; r0 + 32 <= nr; r0 += 32) {    // 16 rows being added while the next 16 are on their way from LDS
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) b[i] = tl[r0 + 16 + i][lane];
-                        if (pass == 1) {                                  // the squares first: off the dependent add chain
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) { const double dlt = a[i] - mean; a[i] = dlt * dlt; }
-                        }
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) acc += a[i];
-                        const int nx = (r0 + 48 <= ROWS) ? r0 + 32 : r0 + 16;        // stay inside the buffer
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) a[i] = tl[nx + i][lane];
-                        if (pass == 1) {
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) { const double dlt = b[i] - mean; b[i] = dlt * dlt; }
-                        }
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) acc += b[i];
-                    }
-                    for (; r0 < nr; ++r0) {              // the tail of a ragged last tile
-                        const double x = tl[r0][lane];
-                        if (pass == 0) acc += x;
-                        else { const double dlt = x - mean; acc += dlt * dlt; }
-                    }
+                    acc = vs_sum_tile<false, ROWS>(s_tile[t & 1], lane, nr, mean, acc);
                 }
             } else if (t + 1 < ntile) {
                 store_tile(t + 1);                        // the other buffer: its last reader (tile t - 1) finished before the last barrier

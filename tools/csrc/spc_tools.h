@@ -19,6 +19,8 @@ int spc_stream_copy_f64(void *dst, const void *src, int64_t bytes, void *stream)
  * threads.  Instantiated mixes: 1:1, 1:0, 0:1, 2:1, 4:2, 8:0, 0:7, 14:7, 16:7 (114:7 / 214:7 = 14:7 with 512- /
  * 1024-thread workgroups). */
 int spc_stream_probe(int n_read, int n_write, void *dst, const void *src, int64_t bytes_per_stream, int grid, void *stream);
+/* one wave running `n` dependent fp64 adds (x = x + c); in: >= 32 doubles, out: 64 doubles.  tools/fp64_chain.py */
+int spc_probe_add_chain(void *out, const void *in, int n, void *stream);
 #ifdef __cplusplus
 }
 #endif

@@ -65,9 +65,32 @@ __global__ __launch_bounds__(BLOCK) void k_copy8(double *dst, const double *src,
         dst[i] = src[i];
 }
 
+// Latency of a DEPENDENT fp64 add chain (what bounds k_vnudge_std: numpy's sequential qt.std sums): one wave, `n` adds
+// x = x + c[i & 15] with the addends in registers, result stored so the chain is live.  tools/fp64_chain.py times it.
+__global__ __launch_bounds__(64) void k_add_chain(double *out, const double *in, int n)
+{
+    double c[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c[i] = in[i];
+    double x = in[16 + (threadIdx.x & 15)];
+    for (int i = 0; i < n; i += 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) x = x + c[j];
+    }
+    out[threadIdx.x] = x;
+}
+
 }  // namespace
 
 extern "C" {
+
+int spc_probe_add_chain(void *out, const void *in, int n, void *stream)
+{
+    if (!out || !in || n <= 0) return fail(-1, "%sadd_chain: bad arguments");
+    hipLaunchKernelGGL(k_add_chain, dim3(1), dim3(64), 0, (hipStream_t)stream, (double *)out, (const double *)in, n);
+    return launch_status("k_add_chain");
+}
+
 
 const char *spc_tools_last_error(void) { return g_err; }
 

@@ -222,12 +222,11 @@ def dropin_rate(eng, n_les=1024, steps=30, warmup=5, per_les_steps=5):
     # the reference's transport: ~35 getter / setter calls per column per step (spcpl.py:341-347, 535-542, 748-766)
     # through the UNCHANGED loop shape of splib.step (splib.py:317-332) -- per-LES spcpl calls on a list of LES objects
     gcm2, ens2 = models.make_batched_models(n_les, nG=91, nL=160, seed=3)
-    gcm2.__class__ = models.TimedSyntheticGCM
+    gcm2.__class__ = models.SyntheticGCM
     cpl2 = Coupler(gcm2, [ens2[i] for i in range(n_les)])
     cpl2.step()
     cpl2.step()
     torch.cuda.synchronize()
-    models.model_seconds = 0.0
     t0 = time.perf_counter()
     for _ in range(per_les_steps):
         cpl2.step()
@@ -235,11 +234,8 @@ def dropin_rate(eng, n_les=1024, steps=30, warmup=5, per_les_steps=5):
     wall2 = time.perf_counter() - t0
     out["per_les_protocol"] = {"value": n_les * per_les_steps / wall2, "steps": per_les_steps,
                                "ms_per_step": wall2 / per_les_steps * 1e3,
-                               "value_model_time_subtracted": n_les * per_les_steps / (wall2 - models.model_seconds),
-                               "ms_per_step_models": models.model_seconds / per_les_steps * 1e3,
-                               "note": "`value`: wall time of the reference's loop shape (35 model calls per column and step), model "
-                                       "time NOT subtracted; `value_model_time_subtracted`: minus the time inside the stand-in models' "
-                                       "timed methods (the timing wrappers' own overhead stays on the coupler's side); "
+                               "note": "`value`: wall time of the reference's loop shape (35 model calls per column and step) on the "
+                                       "synthetic stand-in models, THEIR getters / setters included (NumPy row copies, request objects); "
                                        "`value_null_models`: the same loop on models whose methods cost nothing = the coupler's and "
                                        "driver's own per-column cost, PCIe and kernels included"}
     # the coupler's OWN per-column cost: the same loop on models whose methods cost nothing (no subtraction needed)

@@ -390,10 +390,9 @@ class _LESRow:
     def p(self):
         return {k: v[self._i] for k, v in self._e.p.items()}
 
-    @_timed
     def get_cloudfraction(self, indices, return_request=False):
-        idx = numpy.clip(numpy.asarray(indices), 0, self._e.nL - 1)
-        return _ret(self._e.A_lev[self._i][idx], return_request)
+        v = self._e.A_lev[self._i].take(indices, mode="clip")          # like splib/spdummy.py:319-321
+        return ImmediateRequest(v) if return_request else v
 
     def evolve_model(self, t, exactEnd=True):
         self._e.evolve_model_batched(t)         # the ensemble advances as one; later rows find it already there
@@ -406,20 +405,21 @@ class _LESRow:
 def _row_getter(key):
     def get(self, return_request=False):
         v = self._e.p[key][self._i]
-        return _ret(v.copy() if isinstance(v, numpy.ndarray) else float(v), return_request)
-    return _timed(get)
+        v = v.copy() if v.ndim else float(v)
+        return ImmediateRequest(v) if return_request else v
+    return get
 
 
 def _row_setter(name):
     def set_(self, values, return_request=False):
-        v = numpy.asarray(getattr(values, "number", values), dtype=numpy.float64)
-        t = self._e.tend.get(name)
+        e = self._e
+        t = e.tend.get(name)
         if t is None:
-            t = self._e.tend[name] = self._e._zeros_like_tend(name)
-        t[self._i] = v
+            t = e.tend[name] = e._zeros_like_tend(name)
+        t[self._i] = getattr(values, "number", values)
         self.received.append(name)
-        return _ret(None, return_request)
-    return _timed(set_)
+        return ImmediateRequest(None) if return_request else None
+    return set_
 
 
 for _m, _k in (("get_profile_U", "U"), ("get_profile_V", "V"), ("get_profile_THL", "THL"), ("get_profile_QT", "QT"),

@@ -21,6 +21,11 @@ class _Plan:
 
 class NullEngine:
     device, dtype = torch.device("cpu"), torch.float64
+    def arena(self, specs, rows=None):
+        from sp_coupler_amd.transfer import Arena
+        return Arena(self.device, specs)
+    def to_devices(self, host_array, rows=None):
+        return torch.from_numpy(numpy.ascontiguousarray(host_array))
     def plan_forward(self, g, zf, p, factor, dt, zh=None, out=None, **kw):
         return _Plan(dict(out))
     def plan_backward(self, g, zf, p, factor, dt, out=None, **kw):
@@ -62,7 +67,7 @@ elif len(sys.argv) > 2 and sys.argv[2] == "null":
     gcm.evolve_model_from_cloud_scheme = lambda: None
     cpl = Coupler(gcm, [NullLES(i + 1, ens.zf_cache, ens.zh_cache, 160) for i in range(n)])
 else:
-    gcm.__class__ = models.TimedSyntheticGCM
+    gcm.__class__ = models.SyntheticGCM
     cpl = Coupler(gcm, [ens[i] for i in range(n)])
 cpl.step(); cpl.step()
 steps = 5

@@ -181,8 +181,8 @@ def dropin_rate(eng, n_les=1024, steps=30, warmup=5, per_les_steps=5):
     import torch
     from sp_coupler_amd import models, spcpl, transfer
     from sp_coupler_amd.driver import Coupler
-    spcpl.set_engine(eng)
-    out = {"n_cols": n_les, "levels": "91<->160", "unit": "column-exchanges/s",
+    spcpl.set_engine(None)                   # the engine spcpl.get_engine() picks by itself: what a drop-in user gets
+    out = {"n_cols": n_les, "levels": "91<->160", "unit": "column-exchanges/s", "engine": type(spcpl.get_engine()).__name__,
            "note": "wall time of Coupler.step minus time inside model methods; includes H2D/D2H of every step"}
     gcm, ens = models.make_batched_models(n_les, nG=91, nL=160, seed=3)
     cpl = Coupler(gcm, ens)
@@ -252,6 +252,32 @@ def dropin_rate(eng, n_les=1024, steps=30, warmup=5, per_les_steps=5):
     wall3 = time.perf_counter() - t0
     out["per_les_protocol"]["value_null_models"] = n_les * per_les_steps / wall3
     out["per_les_protocol"]["ms_per_step_null_models"] = wall3 / per_les_steps * 1e3
+    # the same batched-protocol step at T159 size (config 3's 35 718 columns: 1.1 GB over PCIe per step), with
+    # get_engine()'s default and with the opt-in chunked pipeline over 4 streams (multi.streamed_engine, SPC_STREAMS=4)
+    big = {}
+    for label, streams in (("default", None), ("pipelined_4_streams", "4")):
+        if streams is None:
+            os.environ.pop("SPC_STREAMS", None)
+        else:
+            os.environ["SPC_STREAMS"] = streams
+        spcpl.set_engine(None)
+        gcm4, ens4 = models.make_batched_models(35718, nG=91, nL=160, seed=5)
+        cpl4 = Coupler(gcm4, ens4)
+        for _ in range(2):
+            cpl4.step()
+        torch.cuda.synchronize()
+        models.model_seconds = 0.0
+        t0 = time.perf_counter()
+        for _ in range(5):
+            cpl4.step()
+        torch.cuda.synchronize()
+        w4 = time.perf_counter() - t0
+        big[label] = {"value": 35718 * 5 / (w4 - models.model_seconds), "ms_per_step_coupler": (w4 - models.model_seconds) / 5 * 1e3,
+                      "ms_per_step_models": models.model_seconds / 5 * 1e3, "engine": type(spcpl.get_engine()).__name__,
+                      "chunks": getattr(spcpl.get_engine(), "devices_for", lambda n: 1)(35718)}
+        del cpl4, gcm4, ens4
+    os.environ.pop("SPC_STREAMS", None)
+    out["batched_protocol_35718_columns"] = big
     spcpl.set_engine(None)
     return out
 

@@ -82,8 +82,11 @@ class _Plan:
         self.args.factor, self.args.dt = float(factor), float(dt)
 
     def launch(self, stream=None):
-        """Enqueue the kernel on ``stream`` (default: torch's current stream). Returns outputs dict."""
+        """Enqueue the kernel on ``stream`` (default: the engine's own stream if it has one, else torch's current
+        stream of the engine's device). Returns outputs dict."""
         eng = self.engine
+        if stream is None:
+            stream = eng.stream
         with torch.cuda.device(eng.device):          # occupancy queries + launch on the engine's device
             rc = self._fn(*self._call, _stream_ptr(stream, eng.device))
         if rc:
@@ -143,7 +146,11 @@ class Engine:
     """One engine per (device, dtype). ``dtype`` is the arithmetic type of the path: float64 as in
     the reference (AMUSE quantities wrap float64 arrays), float32 for the tolerance sweep."""
 
-    def __init__(self, device=None, dtype=torch.float64):
+    def __init__(self, device=None, dtype=torch.float64, stream=None):
+        """``stream``: a ``torch.cuda.Stream`` every plan of this engine launches on (None: the current stream at launch
+        time) -- several engines with their own streams on ONE device pipeline a large batch chunk by chunk
+        (multi.streamed_engine: the upload of chunk c + 1 overlaps the kernel and the download of chunk c)."""
+        self.stream = stream
         self.lib = _abi.load_library()          # raises SpcLibraryError if the HIP extension is missing
         if dtype not in _DTYPES:
             raise ValueError("dtype must be torch.float64 or torch.float32")
@@ -179,7 +186,7 @@ class Engine:
         from .transfer import Arena
         return Arena(self.device, specs)
 
-    def to_devices(self, host_array, rows=None):
+    def to_devices(self, host_array, rows=None, n_cols=None):
         import numpy
         return torch.from_numpy(numpy.ascontiguousarray(host_array)).to(self.device, self.dtype)
 

@@ -82,15 +82,24 @@ class MultiDeviceEngine:
         return b + [n] * (len(self.engines) - k)          # unused devices get empty blocks
 
     def arena(self, specs, rows):
-        return ShardedArena([e.device for e in self.engines], self.bounds_for(rows), specs, rows)
+        if self.devices_for(rows) == 1:              # everything on the primary engine: its plain single-copy arena
+            return self.primary.arena(specs, rows)
+        return ShardedArena([e.device for e in self.engines], self.bounds_for(rows), specs, rows,
+                            streams=[getattr(e, "stream", None) for e in self.engines])
 
-    def to_devices(self, host_array, rows=None):
-        """a host array on every device: replicated (``rows`` None: the shared LES grid) or row-sharded"""
+    def to_devices(self, host_array, rows=None, n_cols=None):
+        """a host array on every device: replicated (``rows`` None: the shared LES grid) or row-sharded.  A batch that
+        stays on the primary engine (``n_cols`` / ``rows`` below the threshold) gets a plain tensor."""
+        if self.devices_for(rows if rows is not None else (n_cols if n_cols is not None else self.min_cols_per_device * 2)) == 1:
+            return self.primary.to_devices(host_array, rows)
         t = torch.from_numpy(host_array)
         if rows is None:
-            return Sharded([t.to(e.device, e.dtype) for e in self.engines], None)
-        b = self.bounds_for(rows)
-        return Sharded([t[b[i]:b[i + 1]].to(e.device, e.dtype) for i, e in enumerate(self.engines)], b)
+            out = Sharded([t.to(e.device, e.dtype) for e in self.engines], None)
+        else:
+            b = self.bounds_for(rows)
+            out = Sharded([t[b[i]:b[i + 1]].to(e.device, e.dtype) for i, e in enumerate(self.engines)], b)
+        self.synchronize()                            # made on the current streams, used on the engines' own
+        return out
 
     # -- plans: one per device that holds rows ----------------------------------------------------------------------
     def _plans(self, make, example):
@@ -110,12 +119,16 @@ class MultiDeviceEngine:
 
     def plan_forward(self, gcm, zf, prof, factor, dt, zh=None, out=None, **kw):
         ex = gcm["T"]
+        if not isinstance(ex, Sharded):
+            return self.primary.plan_forward(gcm, zf, prof, factor, dt, zh=zh, out=out, **kw)
         plans = self._plans(lambda e, d: e.plan_forward(_parts_of(gcm, d), _part(zf, d), _parts_of(prof, d), factor, dt,
                                                         zh=_part(zh, d), out=_parts_of(out, d), **kw), ex)
         return MultiPlan(plans, self._outputs(plans, ex.bounds))
 
     def plan_backward(self, gcm, zf, prof, factor, dt, Zf=None, zh=None, Zh=None, out=None, **kw):
         ex = gcm["T"]
+        if not isinstance(ex, Sharded):
+            return self.primary.plan_backward(gcm, zf, prof, factor, dt, Zf=Zf, zh=zh, Zh=Zh, out=out, **kw)
         plans = self._plans(lambda e, d: e.plan_backward(_parts_of(gcm, d), _part(zf, d), _parts_of(prof, d), factor, dt,
                                                          Zf=_part(Zf, d), zh=_part(zh, d), Zh=_part(Zh, d),
                                                          out=_parts_of(out, d), **kw), ex)
@@ -123,11 +136,15 @@ class MultiDeviceEngine:
 
     def plan_diagnostics(self, gcm, zf=None, prof=None, out=None, **kw):
         ex = gcm["T"]
+        if not isinstance(ex, Sharded):
+            return self.primary.plan_diagnostics(gcm, zf, prof, out=out, **kw)
         plans = self._plans(lambda e, d: e.plan_diagnostics(_parts_of(gcm, d), _part(zf, d), _parts_of(prof, d),
                                                             out=_parts_of(out, d), **kw), ex)
         return MultiPlan(plans, self._outputs(plans, ex.bounds))
 
     def plan_cloud_indices(self, zh, Zh, out=None, **kw):
+        if not isinstance(Zh, Sharded):
+            return self.primary.plan_cloud_indices(zh, Zh, out=out, **kw)
         plans = self._plans(lambda e, d: e.plan_cloud_indices(_part(zh, d), _part(Zh, d), out=_part(out, d), **kw), Zh)
         return MultiPlan(plans, self._outputs(plans, Zh.bounds))
 
@@ -140,12 +157,13 @@ class MultiDeviceEngine:
         return fp, bp
 
     # -- convenience / slow paths: the whole batch on the primary device ----------------------------------------------
-    @staticmethod
-    def whole(x, device):
+    def whole(self, x, device):
+        """x (tensor / Sharded / dict of them) as whole tensors on ``device``; the engines' streams are drained first"""
         if isinstance(x, Sharded):
+            self.synchronize()
             return x.gather(device)
         if isinstance(x, dict):
-            return {k: MultiDeviceEngine.whole(v, device) for k, v in x.items()}
+            return {k: self.whole(v, device) for k, v in x.items()}
         return x
 
     def forward(self, gcm, zf, prof, factor, dt, **kw):
@@ -174,7 +192,24 @@ class MultiDeviceEngine:
     def synchronize(self):
         for e in self.engines:
             if e.device.type == "cuda":
-                torch.cuda.synchronize(e.device)
+                st = getattr(e, "stream", None)
+                if st is not None:
+                    st.synchronize()
+                else:
+                    torch.cuda.current_stream(e.device).synchronize()
+
+
+def streamed_engine(device=None, n_streams=4, dtype=torch.float64, min_cols_per_chunk=4096):
+    """ONE GPU, a large batch pipelined chunk by chunk: ``n_streams`` engines on the same device, the first on torch's
+    current stream and the others on streams of their own, behind a MultiDeviceEngine -- the same row-block machinery as
+    for several GPUs.  The copies and launches of chunk c all sit on stream c, so the upload of chunk c + 1 (H2D DMA
+    engine) overlaps the kernel and the download of chunk c (D2H engine): PCIe runs in both directions at once.  Batches
+    of fewer than 2 x ``min_cols_per_chunk`` columns stay in one piece on the first engine (small copies cost more than the
+    overlap gains)."""
+    from .engine import Engine
+    dev = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+    engines = [Engine(dev, dtype=dtype)] + [Engine(dev, dtype=dtype, stream=torch.cuda.Stream(dev)) for _ in range(n_streams - 1)]
+    return MultiDeviceEngine(engines, min_cols_per_device=min_cols_per_chunk)
 
 
 def describe_partition(engine, n):

@@ -68,6 +68,12 @@ def get_engine():
         elif torch.cuda.device_count() > 1 and os.environ.get("SPC_SINGLE_GPU") != "1":
             from .multi import MultiDeviceEngine
             _engine = MultiDeviceEngine()
+        elif int(os.environ.get("SPC_STREAMS", "1")) > 1:
+            # opt-in experiment: one GPU, batches of >= 8192 columns pipelined in chunks over several streams so that PCIe
+            # runs both ways at once (multi.streamed_engine).  Measured at 35 718 columns: 26.9 vs 25.1 ms per step --
+            # no gain (the step is bound by the 1.1 GB it moves at ~50 GB/s either way), so it is not the default
+            from .multi import streamed_engine
+            _engine = streamed_engine(n_streams=int(os.environ["SPC_STREAMS"]))
         else:
             _engine = Engine()
     return _engine
@@ -153,8 +159,8 @@ class StepBuffers:
         if key is None or key != self.grid_key:
             self.zf_host, self.zh_host = zf_host, zh_host
             rows = None if zf_host.ndim == 1 else self.n           # shared grid: replicated; per-column grid: row-sharded
-            self.zf = self.engine.to_devices(zf_host, rows)
-            self.zh = self.engine.to_devices(zh_host, rows)
+            self.zf = self.engine.to_devices(zf_host, rows, n_cols=self.n)
+            self.zh = self.engine.to_devices(zh_host, rows, n_cols=self.n)
             self.grid_key = key
             self.plans = {}
 

@@ -128,6 +128,9 @@ class Sharded:
     def gather(self, device=None):
         """the whole array on ONE device (slow paths: diagnostics for the spifs writer, convert_profiles)"""
         device = self.parts[0].device if device is None else device
+        for p in self.parts:                      # the parts may have been produced on other streams / devices
+            if p.device.type == "cuda":
+                torch.cuda.synchronize(p.device)
         if self.bounds is None:
             return self.parts[0].to(device)
         return torch.cat([p.to(device) for p in self.parts if p.shape[0]], dim=0)
@@ -143,9 +146,10 @@ class ShardedArena:
 
     ALIGN = Arena.ALIGN
 
-    def __init__(self, devices, bounds, specs, rows):
+    def __init__(self, devices, bounds, specs, rows, streams=None):
         self.devices = [torch.device(d) for d in devices]
         self.device = self.devices[0]
+        self.streams = list(streams) if streams is not None else [None] * len(self.devices)   # per "device": its own stream or None
         self.bounds, self.rows = list(bounds), rows
         off, lay = 0, []
         for name, shape, dtype in specs:
@@ -178,6 +182,14 @@ class ShardedArena:
             self.order.append(name)
         self.done = [None] * len(self.devices)
 
+    def _on(self, di):
+        """context in which device di's copies are issued: its device, and its own stream if it has one"""
+        dev = self.devices[di]
+        if dev.type != "cuda":
+            return _Nothing()
+        st = self.streams[di]
+        return torch.cuda.stream(st) if st is not None else torch.cuda.device(dev)
+
     def _names(self, upto, start):
         i0 = 0 if start is None else self.order.index(start)
         i1 = len(self.order) if upto is None else self.order.index(upto) + 1
@@ -189,7 +201,7 @@ class ShardedArena:
             lo, hi = self.bounds[di], self.bounds[di + 1]
             if hi == lo:
                 continue
-            with torch.cuda.device(dev) if dev.type == "cuda" else _Nothing():
+            with self._on(di):
                 for name in names:
                     self.d[name].parts[di].copy_(self.h[name][lo:hi], non_blocking=True)
 
@@ -199,7 +211,7 @@ class ShardedArena:
             lo, hi = self.bounds[di], self.bounds[di + 1]
             if hi == lo:
                 continue
-            with torch.cuda.device(dev) if dev.type == "cuda" else _Nothing():
+            with self._on(di):
                 for name in names:
                     self.h[name][lo:hi].copy_(self.d[name].parts[di], non_blocking=True)
                 if dev.type == "cuda":

@@ -60,7 +60,7 @@ class OracleEngine:
         from sp_coupler_amd.transfer import Arena
         return Arena(self.device, specs)
 
-    def to_devices(self, host_array, rows=None):
+    def to_devices(self, host_array, rows=None, n_cols=None):
         return torch.from_numpy(numpy.ascontiguousarray(host_array)).to(self.device, self.dtype)
 
     def plan_forward(self, g, zf, p, factor, dt, zh=None, **kw):

@@ -109,3 +109,30 @@ def test_multi_device_exchange_plans_equal_the_single_engine_plans_bitwise():
     for plan, mplan in ((fp, mfp), (bp, mbp)):
         for k, t in plan.outputs.items():
             assert numpy.array_equal(t.cpu().numpy(), mplan.outputs[k].gather().cpu().numpy(), equal_nan=True), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batched,cplsurf", [(True, True), (False, False)])
+def test_one_gpu_pipelined_over_streams_equals_the_plain_engine(batched, cplsurf):
+    """multi.streamed_engine: chunks of the batch on streams of their own (upload of chunk c + 1 overlapping kernel and
+    download of chunk c) -- what spcpl.get_engine() gives a one-GPU process for large batches -- against a plain Engine"""
+    from sp_coupler_amd.engine import Engine
+    from sp_coupler_amd.multi import streamed_engine
+    ref = _closed_loop(Engine("cuda:0"), 900, 3, batched, cplsurf, nG=91, nL=160)
+    st = streamed_engine("cuda:0", n_streams=3, min_cols_per_chunk=200)
+    assert st.devices_for(900) == 3 and [e.stream is None for e in st.engines] == [True, False, False]
+    got = _closed_loop(st, 900, 3, batched, cplsurf, nG=91, nL=160)
+    for var in ref[0]:
+        assert numpy.array_equal(ref[0][var], got[0][var], equal_nan=True), var
+    assert numpy.array_equal(ref[2], got[2]) and got[3] == ("ShardedArena", ["MultiPlan"])
+    # a batch below the threshold stays in one piece on the first engine: plain arenas, plain plans
+    small = _closed_loop(streamed_engine("cuda:0", n_streams=4), 300, 2, batched, cplsurf, nG=91, nL=160)
+    assert small[3][0] == "Arena" and "MultiPlan" not in small[3][1]
+
+
+@pytest.mark.gpu
+def test_bench_in_process_extra_runs_on_two_engines():
+    import argparse
+    import bench
+    r = bench.in_process_all_gpus([0, 0], 1.0, 900.0, argparse.Namespace(cols=6000, cols_per_block=0, steps=3, warmup=1))
+    assert r["value"] > 0 and r["distinct_devices"] == 1 and "rows 0-3000" in r["partition"]

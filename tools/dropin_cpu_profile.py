@@ -24,7 +24,7 @@ class NullEngine:
     def arena(self, specs, rows=None):
         from sp_coupler_amd.transfer import Arena
         return Arena(self.device, specs)
-    def to_devices(self, host_array, rows=None):
+    def to_devices(self, host_array, rows=None, n_cols=None):
         return torch.from_numpy(numpy.ascontiguousarray(host_array))
     def plan_forward(self, g, zf, p, factor, dt, zh=None, out=None, **kw):
         return _Plan(dict(out))

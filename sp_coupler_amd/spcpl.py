@@ -622,6 +622,14 @@ def _write_forward(batch):
     batch.fwd_written = True
 
 
+def _attach_heights(batch, les, i):
+    """les.gcm_Zf / les.gcm_Zh (spcpl.py:200-201) as lazy rows of THIS batch, valid for every later step of it (a concrete
+    array stored here would go stale: the reference re-assigns them in every set_les_forcings, this path does not)"""
+    z = getattr(les, "gcm_Zf", None)
+    if not (isinstance(z, LazyRow) and z._batch is batch and z._i == i):
+        les.gcm_Zf, les.gcm_Zh = LazyRow(batch, "Zf", i), LazyRow(batch, "Zh", i)
+
+
 def convert_profiles(les, write=True):
     """splib/spcpl.py:171-246: (u, v, thl, qt, ps, ql) for one column; caches les.gcm_Zf / gcm_Zh."""
     batch = _batch_of(les)
@@ -634,8 +642,7 @@ def convert_profiles(les, write=True):
         res = eng.forward(batch.gcm, batch.zf, dummy, 0.0, 1.0, want_profiles=True, want_heights=True)
         batch.conv = {k: _to_host(res[k]) for k in ("u", "v", "thl", "qt", "ps", "ql_ref", "Zf", "Zh")}
     c = batch.conv
-    les.gcm_Zf = _wrap("Zf", c["Zf"][i])                                     # spcpl.py:200
-    les.gcm_Zh = _wrap("Zh", c["Zh"][i])                                     # spcpl.py:201
+    _attach_heights(batch, les, i)                                           # spcpl.py:200-201
     return (_wrap("u", c["u"][i]), _wrap("v", c["v"][i]), _wrap("thl", c["thl"][i]), _wrap("qt", c["qt"][i]),
             _wrap("ps", c["ps"][i]), _wrap("ql", c["ql_ref"][i]))
 
@@ -649,6 +656,7 @@ def set_les_forcings(les, gcm, asynchronous, firststep, profile, dt_gcm, factor,
     except AttributeError:                       # a per-column face of an ensemble, or gather_gcm_data() not called
         batch = _batch_of(les)
         i = batch.index_of(les)
+        _attach_heights(batch, les, i)
     raw = batch.fwd_raw
     if (raw is None or raw[0] is not firststep or raw[1] is not dt_gcm or raw[2] is not factor
             or raw[3] is not couple_surface or raw[4] != batch.profile_generation):

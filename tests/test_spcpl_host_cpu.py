@@ -83,7 +83,15 @@ def test_per_les_calls_need_all_profiles_and_stale_profiles_are_not_reused():
     spcpl.gather_gcm_data(gcm, les_models[:2], False)
     b3 = spcpl.current_batch()
     assert b3 is not b2 and b3.n == 2 and len(b3.profiles) == 2 and les_models[0]._spc_batch is b3
+    # convert_profiles (init path) must not freeze the heights: after the next gather they are those of the NEW GCM state
+    spcpl.convert_profiles(les_models[0], write=False)
+    z_old = numpy.array(les_models[0].gcm_Zf)
+    gcm.state["Zgfull"][les_models[0].grid_index] += 98.1                  # + 10 m at every full level
+    spcpl.gather_gcm_data(gcm, les_models[:2], False)
+    assert numpy.allclose(numpy.asarray(les_models[0].gcm_Zf) - z_old, 10.0)
+    b3 = spcpl.current_batch()
     # heights are computed on first read, per step, and behave like the float64 row
+    spcpl.gather_gcm_data(gcm, les_models[:2], False)
     zf = les_models[0].gcm_Zf
     assert b3.diag_host is None and zf.shape == (19,) and b3.diag_host is not None
     assert numpy.array_equal(numpy.asarray(zf), b3.diag_host["Zf"][0]) and float(zf[0]) > float(zf[-1]) and len(les_models[0].gcm_Zh) == 20

@@ -32,9 +32,6 @@ def main():
     ap.add_argument("--min-ms", type=float, default=10.0, help="timed region at least this long (iters is raised to fit)")
     ap.add_argument("--dtype", default="f64")
     ap.add_argument("--tag", default="")
-    ap.add_argument("--variants", default="", help="semicolon list of kernel variants to A/B in this process: "
-                    "'v1' (first-generation kernels) or 'cb,block' of a spc_v2.hpp instantiation; optional ':r0' / ':r1' "
-                    "suffix = XCD remap off / on")
     a = ap.parse_args()
     nG, nL = (int(x) for x in a.levels.split(","))
     dtype = torch.float64 if a.dtype == "f64" else torch.float32
@@ -53,17 +50,7 @@ def main():
             g = {k: torch.from_numpy(v).to(eng.device, dtype) for k, v in gcm.items()}
             p = {k: torch.from_numpy(v).to(eng.device, dtype) for k, v in prof.items()}
             data.append((g, torch.from_numpy(zf).to(eng.device, dtype), torch.from_numpy(zh).to(eng.device, dtype), p))
-        for cb, var in [(int(x), v) for x in a.cbs.split(",") for v in (a.variants.split(";") if a.variants else [""])]:
-            for k in ("SPC_V2", "SPC_V2_K1", "SPC_V2_K3", "SPC_V2_REMAP", "SPC_V2_PERSIST"):
-                os.environ.pop(k, None)
-            if var:
-                v, _, r = var.partition(":")
-                if v == "v1":
-                    os.environ["SPC_V2"] = "0"
-                else:
-                    os.environ["SPC_V2_K1"] = os.environ["SPC_V2_K3"] = v
-                if r.startswith("r"):
-                    os.environ["SPC_V2_REMAP"] = r[1:]
+        for cb in (int(x) for x in a.cbs.split(",")):
             pl = [eng.plan_exchange(g, zf, zh, p, 1.0, 1.0, 900.0, cols_per_block=cb) for g, zf, zh, p in data]   # as bench.py
             fpl, bpl = [x[0] for x in pl], [x[1] for x in pl]
             res = {}
@@ -86,8 +73,8 @@ def main():
                 e1.record(stream)
                 torch.cuda.synchronize()
                 res[name] = e0.elapsed_time(e1) * 1e3 / iters
-            print("%s %-10s n=%d %d<->%d %s cb=%d rot=%d | K1 %.2f us %.0f GB/s (%.1f%% of 8TB/s) | K3 %.2f us %.0f GB/s (%.1f%%)" % (
-                a.tag, var, n, nG, nL, a.dtype, cb, rot, res["K1"], n * fb / res["K1"] / 1e3, n * fb / res["K1"] / 1e3 / 80,
+            print("%s %-36s n=%d %d<->%d %s cb=%d rot=%d | K1 %.2f us %.0f GB/s (%.1f%% of 8TB/s) | K3 %.2f us %.0f GB/s (%.1f%%)" % (
+                a.tag, fpl[0].describe().split()[0].replace("k_forward", ""), n, nG, nL, a.dtype, cb, rot, res["K1"], n * fb / res["K1"] / 1e3, n * fb / res["K1"] / 1e3 / 80,
                 res["K3"], n * bb / res["K3"] / 1e3, n * bb / res["K3"] / 1e3 / 80), flush=True)
 
 

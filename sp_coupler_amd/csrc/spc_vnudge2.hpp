@@ -229,6 +229,21 @@ template <bool GLOBAL> __global__ __launch_bounds__(VN2_THREADS) void k_vnudge_s
     // the level's state machine on the result.
     const int CW = TL < 64 ? TL : 64;
     volatile double *const vleaf = my_leaf;
+    // this lane's steps of the combine program are the same in every evaluation round: read them from the LDS tables ONCE
+    // (up to two steps per lane and chunk shape: trees of <= 2 CW + 1 leaves, i.e. every plane the LDS path takes and the
+    // 128-leaf chunks of the streamed path); taller trees walk the tables
+    int tq_rnd[2][2] = {{0, 0}, {0, 0}}, tq_l[2][2] = {{0, 0}, {0, 0}}, tq_r[2][2] = {{0, 0}, {0, 0}};
+    bool tq_fast[2];
+#pragma unroll
+    for (int sh = 0; sh < 2; ++sh) {
+        const int nl = s_nleaf[sh];
+        tq_fast[sh] = nl - 1 <= 2 * CW;
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int t = tl + qq * CW;
+            if (tl < CW && t + 1 < nl) { tq_rnd[sh][qq] = s_rnd[sh][t]; tq_l[sh][qq] = s_pl[sh][t]; tq_r[sh][qq] = s_pr[sh][t]; }
+        }
+    }
     for (;;) {
         if (own) {
             double x = 0.0;
@@ -299,13 +314,24 @@ template <bool GLOBAL> __global__ __launch_bounds__(VN2_THREADS) void k_vnudge_s
             __syncthreads();
             if (tl < CW && mode != 0) {                             // numpy's tree, one dependency round at a time
                 const int nround = s_nround[shape];
-                for (int rd = 1; rd <= nround; ++rd) {
-                    for (int t = tl; t + 1 < nleaf; t += CW)
-                        if (s_rnd[shape][t] == rd) {
-                            const int l = s_pl[shape][t], r = s_pr[shape][t];
-                            vleaf[l] = vleaf[l] + vleaf[r];
-                        }
-                    __builtin_amdgcn_wave_barrier();
+                if (shape ? tq_fast[1] : tq_fast[0]) {
+                    const int r0 = shape ? tq_rnd[1][0] : tq_rnd[0][0], r1 = shape ? tq_rnd[1][1] : tq_rnd[0][1];
+                    const int l0 = shape ? tq_l[1][0] : tq_l[0][0], l1 = shape ? tq_l[1][1] : tq_l[0][1];
+                    const int p0 = shape ? tq_r[1][0] : tq_r[0][0], p1 = shape ? tq_r[1][1] : tq_r[0][1];
+                    for (int rd = 1; rd <= nround; ++rd) {
+                        if (r0 == rd) vleaf[l0] = vleaf[l0] + vleaf[p0];
+                        if (r1 == rd) vleaf[l1] = vleaf[l1] + vleaf[p1];
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                } else {
+                    for (int rd = 1; rd <= nround; ++rd) {
+                        for (int t = tl; t + 1 < nleaf; t += CW)
+                            if (s_rnd[shape][t] == rd) {
+                                const int l = s_pl[shape][t], r = s_pr[shape][t];
+                                vleaf[l] = vleaf[l] + vleaf[r];
+                            }
+                        __builtin_amdgcn_wave_barrier();
+                    }
                 }
                 if (own) total += vleaf[0];
             }

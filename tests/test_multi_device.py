@@ -13,7 +13,7 @@ from sp_coupler_amd.multi import MultiDeviceEngine, describe_partition
 from sp_coupler_amd.sharding import shard_bounds
 
 
-def _closed_loop(engine, n_les, nsteps, batched, cplsurf=False, conservative=False, nG=19, nL=40):
+def _closed_loop(engine, n_les, nsteps, batched, cplsurf=False, conservative=False, nG=19, nL=40, per_column_grid=False):
     from sp_coupler_amd.driver import Coupler
     spcpl.set_engine(engine)
     try:
@@ -21,6 +21,9 @@ def _closed_loop(engine, n_les, nsteps, batched, cplsurf=False, conservative=Fal
             gcm, les = models.make_batched_models(n_les, nG=nG, nL=nL, seed=5)
         else:
             gcm, les = models.make_models(n_les, nG=nG, nL=nL, seed=5)
+            if per_column_grid:          # every LES on a grid of its own: zf / zh become [n x nL] arrays, sharded by rows too
+                for i, m in enumerate(les):
+                    m.zf_cache, m.zh_cache = m.zf_cache * (1 + 0.01 * i), m.zh_cache * (1 + 0.01 * i)
         cpl = Coupler(gcm, les, cplsurf=cplsurf, conservative_coarsening=conservative, les_forcing_factor=0.9)
         cpl.run(nsteps)
         b = spcpl.current_batch()
@@ -47,6 +50,41 @@ def test_row_blocks_over_several_engines_equal_one_engine(ndev, n_les, batched, 
         assert numpy.array_equal(ref[1][0], got[1][0]) and numpy.array_equal(ref[1][1], got[1][1])
     assert numpy.array_equal(ref[2], got[2])
     assert ref[3][0] == "Arena" and got[3] == ("ShardedArena", ["MultiPlan"]), (ref[3], got[3])
+
+
+def test_per_column_les_grids_are_sharded_with_their_rows():
+    from tests.fake_engine import OracleEngine
+    ref = _closed_loop(OracleEngine(), 7, 2, False, per_column_grid=True)
+    got = _closed_loop(MultiDeviceEngine([OracleEngine() for _ in range(3)], min_cols_per_device=1), 7, 2, False, per_column_grid=True)
+    for var in ref[0]:
+        assert numpy.array_equal(ref[0][var], got[0][var], equal_nan=True), var
+    assert numpy.array_equal(ref[2], got[2]) and got[3][0] == "ShardedArena"
+
+
+def test_sharded_arena_partial_copies_and_host_only_rows():
+    """transfer.ShardedArena: one pinned host buffer with full-length views, rows [0, rows) mirrored block-wise per device
+    (host rows beyond `rows` -- the GCM's extra output columns -- stay host-only), copies of a sub-range of the arrays"""
+    import torch
+    from sp_coupler_amd.transfer import ShardedArena
+    a = ShardedArena(["cpu", "cpu", "cpu"], [0, 3, 5, 5], [("A", (7, 4), torch.float64), ("B", (5,), torch.int32),
+                                                             ("C", (5, 2), torch.float64)], rows=5)
+    a.hn["A"][:] = numpy.arange(28).reshape(7, 4)
+    a.hn["B"][:] = numpy.arange(5)
+    a.hn["C"][:] = -1.0
+    a.upload(upto="B")
+    assert [tuple(p.shape) for p in a.d["A"].parts] == [(3, 4), (2, 4), (0, 4)] and a.d["A"].shape == (5, 4)
+    assert torch.equal(a.d["A"].gather(), torch.from_numpy(a.hn["A"][:5])) and a.d["B"].parts[1].tolist() == [3, 4]
+    for p in a.d["C"].parts:
+        p.fill_(7.0)
+    a.hn["A"][:] = 0
+    a.download(upto="C", start="C")                       # only C comes back
+    assert (a.hn["C"] == 7.0).all() and (a.hn["A"] == 0).all()
+    a.download(upto="A")
+    assert numpy.array_equal(a.hn["A"][:5], numpy.arange(20).reshape(5, 4)) and (a.hn["A"][5:] == 0).all()
+    with pytest.raises(IndexError):
+        a.d["A"][1:3]
+    with pytest.raises(ValueError):
+        ShardedArena(["cpu"], [0, 5], [("x", (3,), torch.float64)], rows=5)
 
 
 def test_small_batches_stay_on_one_device_and_the_partition_is_the_sharding_one():

@@ -11,6 +11,7 @@ Same function names, argument meaning and return values as the reference module,
     get_cloud_fraction(les)                                                                    spcpl.py:22
     set_gcm_tendencies(gcm, les, profile, dt_gcm, factor=1, write=True, conservative=False)    spcpl.py:388
     write_les_profiles(les) / set_les_state(les, u, v, thl, qt, ps=None)                       spcpl.py:574/274
+    set_gcm_tendencies_from_file(gcm, les)                                                     spcpl.py:558
     convert_surface_fluxes(les) / output_column_conversion(profile)                            spcpl.py:136/251
 
 What differs is WHERE the arithmetic runs: ``gather_gcm_data`` packs every SP column into
@@ -991,6 +992,34 @@ def set_gcm_tendencies_batched(gcm, les_models, profiles, dt_gcm, factor=1, writ
         batch.profiles[id(les)] = profiles[les]
     for les in les_models:
         set_gcm_tendencies(gcm, les, None, dt_gcm, factor, write, conservative)
+
+
+# ---------------------------------------------------------------------------------------------
+# tendencies replayed from spifs: splib/spcpl.py:558-570 ("not used - was thought to be necessary for restarts")
+# ---------------------------------------------------------------------------------------------
+_FILE_TENDENCIES = None      # (path, record, model time) -> what was read, so a per-les loop opens the file once
+
+
+def set_gcm_tendencies_from_file(gcm, les, path=None):
+    """splib/spcpl.py:558-570: the seven GCM tendencies of column ``les`` taken from the spifs record nearest to the GCM's
+    model time (as stored: float32) instead of computed.  ``path``: a spifs file written by ``spio.SpifsWriter`` (default:
+    the active ``spcpl.writer``, flushed first).  The file is read once per (path, model time), not once per column."""
+    global _FILE_TENDENCIES
+    from . import spio
+    if path is None:
+        if writer is None:
+            raise RuntimeError("set_gcm_tendencies_from_file: no spifs file (pass path= or install spcpl.writer)")
+        writer.sync()
+        path = writer.path
+    t = float(_num(gcm.get_model_time()))
+    if _FILE_TENDENCIES is None or _FILE_TENDENCIES[0] != (path, t):
+        ti, tv, gi, data = spio.read_record_nearest(path, t, ["f_" + v for v in _TEND_VARS])
+        log.info("set_gcm_tendencies_from_file() %s %d %s", t, ti, tv)
+        _FILE_TENDENCIES = ((path, t), {int(g): c for c, g in enumerate(gi)}, data)
+    _, col_of, data = _FILE_TENDENCIES
+    c = col_of[int(les.grid_index)]
+    for var in _TEND_VARS:                                                       # spcpl.py:564-570
+        gcm.set_profile_tendency(var, les.grid_index, _wrap("f_" + var, data["f_" + var][c].copy()))
 
 
 # ---------------------------------------------------------------------------------------------

@@ -33,6 +33,7 @@ class SpifsWriter:
     def __init__(self, path, grid_indices, lats, lons, zf, nG, start_time="", with_surf_vars=True):
         self.lock = threading.Lock()                                          # spio.py:24
         self.step = -1                                                        # spio.py:27
+        self.path = path
         self.n = len(grid_indices)
         f = self.f = netcdf_file(path, "w")
         f.createDimension("Time", None)                                       # spio.py:100
@@ -106,3 +107,15 @@ def read_column(path, column):
             elif var.dimensions == ("column",):
                 out[name] = _native(var[column])
     return out
+
+
+def read_record_nearest(path, t, names):
+    """the record whose Time is nearest to ``t`` (what spcpl.set_gcm_tendencies_from_file looks up, splib/spcpl.py:560):
+    returns (record index, its Time, grid_index[column], {name: [column x levels] float64})"""
+    with netcdf_file(path, "r", mmap=False) as f:
+        times = _native(f.variables["Time"][:]).astype(numpy.float64)
+        if times.size == 0:
+            raise ValueError("%s holds no record" % path)
+        ti = int(numpy.abs(times - float(t)).argmin())
+        data = {n: _native(f.variables[n][ti]).astype(numpy.float64) for n in names}
+        return ti, float(times[ti]), _native(f.variables["grid_index"][:]), data

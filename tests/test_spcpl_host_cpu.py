@@ -335,3 +335,36 @@ def test_variance_forcing_on_the_ensemble_path_equals_the_per_les_path():
     spcpl.gather_gcm_data(gcm_b, del_fields, False, write=False)
     with pytest.raises(NotImplementedError, match="get_fields_batched"):
         spcpl.set_les_forcings_batched(del_fields, gcm_b, True, True, None, 900.0, 1.0, False, qt_forcing='variance')
+
+
+def test_set_gcm_tendencies_from_file_replays_the_nearest_record(tmp_path):
+    """splib/spcpl.py:558-570: the tendencies a run wrote to spifs, set again on a GCM from the file (float32 as stored),
+    the record chosen by the GCM's model time"""
+    from sp_coupler_amd import spio
+    from sp_coupler_amd.driver import Coupler
+    gcm, les_models = models.make_models(3, nG=19, nL=160, seed=2)
+    path = str(tmp_path / "spifs.nc")
+    spcpl.writer = spio.SpifsWriter(path, [m.grid_index for m in les_models], [0] * 3, [0] * 3, les_models[0].zf_cache, 19)
+    rec = Recorder(gcm, les_models)
+    Coupler(gcm, les_models, write=True).run(3)
+    want = _by_key(rec.log)                                   # what set_profile_tendency received, per step
+    # replay from the still-open file: model time 900 s -> the record written with Time = 900 (the second step's)
+    gcm2, _ = models.make_models(3, nG=19, nL=160, seed=2)
+    gcm2.model_time = 930.0
+    for les in les_models:
+        spcpl.set_gcm_tendencies_from_file(gcm2, les)
+    spcpl.writer.close()
+    spcpl.writer = None
+    c = spio.read_column(path, 0)
+    ti = int(numpy.abs(c["Time"] - 930.0).argmin())
+    for les in les_models:
+        for var in ("U", "V", "T", "SH", "QL", "QI", "A"):
+            got = gcm2.tendencies[var][les.grid_index]
+            assert numpy.array_equal(got, numpy.asarray(want[("gcm", les.grid_index, "f_" + var)][ti], dtype=numpy.float32).astype(numpy.float64)), var
+    # by path, after the run
+    gcm3, _ = models.make_models(3, nG=19, nL=160, seed=2)
+    spcpl.set_gcm_tendencies_from_file(gcm3, les_models[1], path=path)          # model time 0: the first record
+    assert numpy.array_equal(gcm3.tendencies["T"][les_models[1].grid_index],
+                             numpy.asarray(want[("gcm", les_models[1].grid_index, "f_T")][0], dtype=numpy.float32).astype(numpy.float64))
+    with pytest.raises(RuntimeError, match="no spifs file"):
+        spcpl.set_gcm_tendencies_from_file(gcm3, les_models[1])

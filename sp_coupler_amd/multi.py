@@ -199,19 +199,6 @@ class MultiDeviceEngine:
                     torch.cuda.current_stream(e.device).synchronize()
 
 
-def streamed_engine(device=None, n_streams=4, dtype=torch.float64, min_cols_per_chunk=4096):
-    """ONE GPU, a large batch pipelined chunk by chunk: ``n_streams`` engines on the same device, the first on torch's
-    current stream and the others on streams of their own, behind a MultiDeviceEngine -- the same row-block machinery as
-    for several GPUs.  The copies and launches of chunk c all sit on stream c, so the upload of chunk c + 1 (H2D DMA
-    engine) overlaps the kernel and the download of chunk c (D2H engine): PCIe runs in both directions at once.  Batches
-    of fewer than 2 x ``min_cols_per_chunk`` columns stay in one piece on the first engine (small copies cost more than the
-    overlap gains)."""
-    from .engine import Engine
-    dev = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
-    engines = [Engine(dev, dtype=dtype)] + [Engine(dev, dtype=dtype, stream=torch.cuda.Stream(dev)) for _ in range(n_streams - 1)]
-    return MultiDeviceEngine(engines, min_cols_per_device=min_cols_per_chunk)
-
-
 def describe_partition(engine, n):
     """text for logs / bench output: which rows go where"""
     b = engine.bounds_for(n)

@@ -69,12 +69,6 @@ def get_engine():
         elif torch.cuda.device_count() > 1 and os.environ.get("SPC_SINGLE_GPU") != "1":
             from .multi import MultiDeviceEngine
             _engine = MultiDeviceEngine()
-        elif int(os.environ.get("SPC_STREAMS", "1")) > 1:
-            # opt-in experiment: one GPU, batches of >= 8192 columns pipelined in chunks over several streams so that PCIe
-            # runs both ways at once (multi.streamed_engine).  Measured at 35 718 columns: 26.9 vs 25.1 ms per step --
-            # no gain (the step is bound by the 1.1 GB it moves at ~50 GB/s either way), so it is not the default
-            from .multi import streamed_engine
-            _engine = streamed_engine(n_streams=int(os.environ["SPC_STREAMS"]))
         else:
             _engine = Engine()
     return _engine
@@ -290,8 +284,10 @@ class ColumnBatch:
         self.ql_ref_host = None
 
     def _fill(self, gcm, first=None):
-        """one ``get_profile_fields`` per variable straight into the pinned buffer, ONE host->device copy (spcpl.py:62-75)"""
-        hn, cols, use_out = self.buf.gcm_in.hn, self.cols, self.use_out
+        """one ``get_profile_fields`` per variable straight into the pinned buffer; each variable starts crossing PCIe on
+        the buffer's copy stream as soon as it is there, overlapped with the fetch of the next one (spcpl.py:62-75)"""
+        arena = self.buf.gcm_in
+        hn, cols, use_out = arena.hn, self.cols, self.use_out
         for v in gcm_vars:                                                    # spcpl.py:62-67
             if v == gcm_vars[0] and first is not None:
                 numpy.copyto(hn[v], first)
@@ -299,13 +295,14 @@ class ColumnBatch:
                 gcm.get_profile_fields(v, cols, out=hn[v])
             else:
                 numpy.copyto(hn[v], _num(gcm.get_profile_fields(v, cols)))
+            arena.push(v, "h2d_gcm")                # on the wire while the next variable is being fetched from the GCM
         if self.couple_surface:
             for v in surf_vars:                                               # spcpl.py:69-75
                 if use_out:
                     gcm.get_surface_field(v, cols, out=hn[v])
                 else:
                     numpy.copyto(hn[v], _num(gcm.get_surface_field(v, cols)))
-        self.buf.gcm_in.upload(what="h2d_gcm")
+                arena.push(v, "h2d_gcm")
 
     def reusable_for(self, engine, les_models, cols, couple_surface):
         """same engine, same LES objects in the same order, same GCM columns, same surface switch, buffers still ours"""
@@ -372,10 +369,10 @@ class ColumnBatch:
         return self.row[id(les)]
 
     # ---- LES slab means -> device -------------------------------------------------------------
-    def stack_profiles(self, keys, source, upto=None):
+    def stack_profiles(self, keys, source):
         """per-LES protocol: source(les) -> dict (values, AMUSE-style quantities or async requests).  Rows are written
         straight into the pinned upload buffer (one C loop per variable; the kind of value -- request / quantity / bare
-        array -- is looked at on the FIRST column only); ONE host->device copy for all keys."""
+        array -- is looked at on the FIRST column only); each variable goes on the wire as soon as it is packed."""
         hn = self.buf.les_in.hn
         rows = [source(les) for les in self.les_models]
         for k in keys:
@@ -398,18 +395,17 @@ class ColumnBatch:
                     numpy.stack(vals, out=dst)
                 else:
                     dst[:] = vals
-        self.buf.les_in.upload(upto=upto, what="h2d_les")
+            self.buf.les_in.push(k, "h2d_les")       # on the wire while the next variable is being packed
         return {k: self.buf.les_in.d[k] for k in keys}
 
-    def upload_profiles(self, keys, arrays=None, upto=None):
+    def upload_profiles(self, keys, arrays=None):
         """batched protocol: ``arrays`` (dict key -> [n x ...]) are copied into the upload buffer unless they ARE its
         views already (ensemble getters write there directly); one host->device copy."""
         hn = self.buf.les_in.hn
-        if arrays is not None:
-            for k in keys:
-                if arrays[k] is not hn[k]:
-                    numpy.copyto(hn[k], _num(arrays[k]))
-        self.buf.les_in.upload(upto=upto, what="h2d_les")
+        for k in keys:
+            if arrays is not None and arrays[k] is not hn[k]:
+                numpy.copyto(hn[k], _num(arrays[k]))
+            self.buf.les_in.push(k, "h2d_les")
         return {k: self.buf.les_in.d[k] for k in keys}
 
 
@@ -483,6 +479,7 @@ def gather_gcm_data(gcm, les_models, couple_surface, output_column_indices=None,
 # ---------------------------------------------------------------------------------------------
 _FWD_KEYS = ("U", "V", "THL", "QT", "QL", "PS", "Rain")
 _FWD_CORE = ("f_u", "f_v", "f_thl", "f_qt", "f_ql", "ql_ref", "f_ps", "idx")
+_FWD_PULL = ("f_u", "f_v", "f_thl", "f_qt", "f_ps", "f_ql", "ql_ref", "idx")     # download order = setter order (spcpl.py:341-347)
 _FWD_SURF = ("z0m", "z0h", "wthl", "wqt")
 _DIAG_GCM = ("Zf", "Zh", "Tv", "THL", "QT")       # K5's GCM-level outputs; contiguous in StepBuffers.fwd_out
 
@@ -504,7 +501,14 @@ def _plan(batch, kind, flags, make):
     return plan
 
 
+def _inputs_ready(batch):
+    """the current stream waits for the uploads still in flight on the transfer buffers' copy streams"""
+    batch.buf.gcm_in.fence()
+    batch.buf.les_in.fence()
+
+
 def _launch(batch, plan, what):
+    _inputs_ready(batch)
     if transfer.trace is not None:
         with transfer.trace.region(what, 0, batch.engine.device):
             plan.launch()
@@ -513,7 +517,7 @@ def _launch(batch, plan, what):
     return plan.outputs
 
 
-def forward_batched(batch, profiles, dt_gcm, factor, couple_surface=False):
+def forward_batched(batch, profiles, dt_gcm, factor, couple_surface=False, wait=True):
     """K1 (+fused K2) for every column of ``batch`` -- the LEAN hot-path kernel bench.py times (the six setter
     arrays, f_ps and the index map; with ``couple_surface`` also the surface fluxes).  ``profiles``: dict of device
     tensors U,V,THL,QT,QL [n x nL], PS [n] (views of the step's upload buffer).  Returns dict of HOST arrays: views
@@ -530,7 +534,11 @@ def forward_batched(batch, profiles, dt_gcm, factor, couple_surface=False):
         couple_surface=couple_surface, out=out))
     plan.set_scalars(float(factor), dt)
     _launch(batch, plan, "k1")
-    b.fwd_out.download(upto="wqt" if couple_surface else "idx", what="d2h_forcings")
+    # results come back array by array on the buffer's copy stream; `wait=False`: the caller takes each one when it has
+    # landed (b.fwd_out.ready(name)) and hands it to the model while the next ones are still on the wire
+    b.fwd_out.pull(_FWD_PULL + (("wthl", "wqt") if couple_surface else ()), "d2h_forcings")
+    if wait:
+        b.fwd_out.ready()
     host = {k: b.fwd_out.hn[k] for k in _FWD_CORE}
     if couple_surface:
         host["wthl"], host["wqt"] = b.fwd_out.hn["wthl"], b.fwd_out.hn["wqt"]
@@ -578,7 +586,7 @@ def _ensure_forward(batch, les, firststep, profile, dt_gcm, factor, couple_surfa
                                    "for every LES after stepping it (as splib.step_les_models does) or use "
                                    "set_les_forcings_batched()" % len(missing))
             src = lambda m: batch.profiles[id(m)]               # noqa: E731
-        prof = batch.stack_profiles(_FWD_KEYS, src, upto="Rain")
+        prof = batch.stack_profiles(_FWD_KEYS, src)
         rain_last = numpy.array([float(_num(getattr(m, "rain", 0.0))) for m in batch.les_models])   # spcpl.py:316-319
         host = forward_batched(batch, prof, dt_gcm, factor, couple_surface)
         _finish_forward(batch, host, batch.buf.les_in.hn["Rain"], rain_last, dt_gcm)
@@ -640,6 +648,7 @@ def convert_profiles(les, write=True):
         nL = batch.zf.shape[-1]
         z = torch.zeros(batch.n, nL, device=eng.device, dtype=eng.dtype)
         dummy = {"U": z, "V": z, "THL": z, "QT": z, "QL": z, "PS": torch.zeros(batch.n, device=eng.device, dtype=eng.dtype)}
+        _inputs_ready(batch)
         res = eng.forward(batch.gcm, batch.zf, dummy, 0.0, 1.0, want_profiles=True, want_heights=True)
         batch.conv = {k: _to_host(res[k]) for k in ("u", "v", "thl", "qt", "ps", "ql_ref", "Zf", "Zh")}
     c = batch.conv
@@ -723,22 +732,26 @@ def _ensemble_forcings(ens, firststep, profiles, dt_gcm, factor, couple_surface,
         raise NotImplementedError("qt_forcing='variance' needs the 3-D LES fields: an ensemble must offer get_fields_batched / "
                                   "set_fields_batched (sp_coupler_amd.models docstring), or pass the LES objects as a plain list")
     if firststep:                                                            # spcpl.py:302-308, 321
-        ens.get_profiles_batched(_FWD_KEYS, {k: hn[k] for k in _FWD_KEYS})
-        b.les_in.upload(upto="Rain", what="h2d_les")
+        for k in _FWD_KEYS:                     # variable by variable: each is on the wire while the next is fetched
+            ens.get_profiles_batched((k,), {k: hn[k]})
+            b.les_in.push(k, "h2d_les")
         b.rain_prev = numpy.zeros(batch.n)                                   # `except: rain_last = 0`, spcpl.py:316-319
     elif profiles is None or profiles.get("_buffers") is not b:
         raise RuntimeError("set_les_forcings_batched: pass what get_les_profiles_batched() returned after the last "
                            "LES step (the slab means of this batch geometry are not on the device)")
     dev = b.les_in.d
-    host = forward_batched(batch, dev, dt_gcm, factor, couple_surface)
+    host = forward_batched(batch, dev, dt_gcm, factor, couple_surface, wait=False)
+    # the setters of spcpl.py:341-347 in their order, each as soon as ITS array has landed: the model takes f_u while
+    # f_v ... are still crossing PCIe
+    for key, name in (("U", "f_u"), ("V", "f_v"), ("THL", "f_thl"), ("QT", "f_qt"), ("SP", "f_ps"), ("QL", "f_ql"), ("QLp", "ql_ref")):
+        b.fwd_out.ready(name)
+        ens.set_forcings_batched(**{key: host[name]})
+    b.fwd_out.ready()
+    if couple_surface:                                                       # spcpl.py:359-364
+        ens.set_forcings_batched(Z0M_surf=host["z0m"], Z0H_surf=host["z0h"], WT_surf=host["wthl"], WQ_surf=host["wqt"])
     _finish_forward(batch, host, hn["Rain"], getattr(b, "rain_prev", numpy.zeros(batch.n)), dt_gcm)
     b.rain_prev = host["rain"]                                               # les.rain = rain, spcpl.py:324
     batch.ql_ref_host = ens.ql_ref = host["ql_ref"]                          # les.ql_ref = ql, spcpl.py:348
-    kw = dict(U=host["f_u"], V=host["f_v"], THL=host["f_thl"], QT=host["f_qt"], SP=host["f_ps"], QL=host["f_ql"],
-              QLp=host["ql_ref"])                                            # spcpl.py:341-347
-    if couple_surface:                                                       # spcpl.py:359-364
-        kw.update(Z0M_surf=host["z0m"], Z0H_surf=host["z0h"], WT_surf=host["wthl"], WQ_surf=host["wqt"])
-    ens.set_forcings_batched(**kw)
     if write and writer is not None:
         _write_forward(batch)
     if qt_forcing == 'variance' and float(_num(ens.model_time)) > 0:         # spcpl.py:377-382
@@ -850,8 +863,8 @@ def get_les_profiles(les, asynchronous):
 
 def get_les_profiles_batched(les_models, asynchronous=False, diagnostics=False):
     """The 14 getters of spcpl.py:747-767 for ALL columns.  With an LES ensemble (batched protocol): one call per
-    group, written straight into the pinned upload buffer, and ONE host->device copy that serves both this
-    step's K3 and the next step's K1; ``diagnostics`` adds presf, Rhof, Rhobf, QR (conservative coarsening / spifs).
+    variable, written straight into the pinned upload buffer and sent on as soon as it is there (ONE upload of every
+    variable, serving both this step's K3 and the next step's K1); ``diagnostics`` adds presf, Rhof, Rhobf, QR (conservative coarsening / spifs).
     With a plain list of LES objects: dict les -> get_les_profiles(les)."""
     if not _is_ensemble(les_models):
         return {les: get_les_profiles(les, asynchronous) for les in les_models}
@@ -860,9 +873,11 @@ def get_les_profiles_batched(les_models, asynchronous=False, diagnostics=False):
     b = batch.buf
     hn = b.les_in.hn
     keys = _LES_IN_LEVELS + ("PS", "Rain") + (_LES_DIAG_LEVELS if diagnostics else ())
-    ens.get_profiles_batched(keys, {k: hn[k] for k in keys})
+    for k in keys:                              # variable by variable: each is on the wire while the next is fetched
+        ens.get_profiles_batched((k,), {k: hn[k]})
+        b.les_in.push(k, "h2d_les")
     ens.get_cloudfraction_batched(_index_map(batch), hn["A"])                 # spcpl.py:761-765
-    b.les_in.upload(upto=None if diagnostics else "A", what="h2d_les")        # the diagnostics sit at the end
+    b.les_in.push("A", "h2d_les")
     batch.profile_generation += 1
     prof = {k: hn[k] for k in keys + ("A",)}
     prof["_buffers"] = b
@@ -877,7 +892,7 @@ _BWD_OUT = ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A")
 _TEND_VARS = ("U", "V", "T", "SH", "QL", "QI", "A")                            # setter order of spcpl.py:535-542
 
 
-def backward_batched(batch, profiles, dt_gcm, factor=1, conservative=False):
+def backward_batched(batch, profiles, dt_gcm, factor=1, conservative=False, wait=True):
     """K3 (K4 when ``conservative``) for every column of ``batch``; ``profiles``: dict of device tensors
     T,QT,QL,QL_ice,U,V [n x nL], A [n x nG] (+ Rhobf for conservative).  Zf is recomputed from the geopotential
     in-kernel (same arithmetic as the forward pass: no height round trip).  Returns dict of HOST arrays, views
@@ -891,7 +906,9 @@ def backward_batched(batch, profiles, dt_gcm, factor=1, conservative=False):
         batch.gcm, batch.zf, prof, float(factor), dt, Zf=None, conservative=conservative, zh=batch.zh, out=out))
     plan.set_scalars(float(factor), dt)
     _launch(batch, plan, "k4" if conservative else "k3")
-    b.bwd_out.download(what="d2h_tendencies")
+    b.bwd_out.pull(tuple("f_" + v for v in _TEND_VARS) + ("start_index",), "d2h_tendencies")
+    if wait:
+        b.bwd_out.ready()
     batch.bwd_rows = None
     return {k: b.bwd_out.hn[k] for k in _BWD_OUT + ("start_index",)}
 
@@ -910,7 +927,7 @@ def _ensure_backward(batch, les, profile, dt_gcm, factor, write, conservative):
         keys = _BWD_KEYS + (("Rhobf",) if conservative else ())
         if with_file:
             keys = keys + tuple(k for k in ("THL", "presf", "Rhof", "Rhobf", "QR") if k not in keys)
-        prof = batch.stack_profiles(keys, src, upto=None if (with_file or conservative) else "A")
+        prof = batch.stack_profiles(keys, src)
         batch.bwd = backward_batched(batch, prof, dt_gcm, factor, conservative)
         batch.bwd_key = key
         if with_file:
@@ -955,6 +972,7 @@ def _write_backward(batch, prof):
     """spifs rows of set_gcm_tendencies for ALL columns (spcpl.py:412-425, 545-555). ``prof``: device tensors of
     the slab means incl. THL, presf, Rhof, Rhobf, QR."""
     b, n = batch.bwd, batch.n
+    _inputs_ready(batch)
     d = batch.engine.diagnostics(batch.gcm, batch.zf, prof)                                  # K5: t, ql_water
     h = _to_host
     writer.write(u=h(prof["U"]), v=h(prof["V"]), presf=h(prof["presf"]), rhof=h(prof["Rhof"]),
@@ -976,13 +994,15 @@ def set_gcm_tendencies_batched(gcm, les_models, profiles, dt_gcm, factor=1, writ
             raise RuntimeError("set_gcm_tendencies_batched: pass what get_les_profiles_batched() returned")
         if (write and writer is not None or conservative) and "Rhobf" not in profiles:
             raise RuntimeError("conservative coarsening / spifs output need get_les_profiles_batched(diagnostics=True)")
-        batch.bwd = backward_batched(batch, b.les_in.d, dt_gcm, factor, conservative)
+        batch.bwd = backward_batched(batch, b.les_in.d, dt_gcm, factor, conservative, wait=False)
+        if hasattr(gcm, "set_profile_tendencies"):
+            for var in _TEND_VARS:                                               # spcpl.py:535-542, each as it lands
+                b.bwd_out.ready("f_" + var)
+                gcm.set_profile_tendencies(var, les_models.grid_indices, _wrap("f_" + var, batch.bwd["f_" + var]))
+        b.bwd_out.ready()
         if write and writer is not None:
             _write_backward(batch, b.les_in.d)
-        if hasattr(gcm, "set_profile_tendencies"):
-            for var in ("U", "V", "T", "SH", "QL", "QI", "A"):                   # spcpl.py:535-542
-                gcm.set_profile_tendencies(var, les_models.grid_indices, _wrap("f_" + var, batch.bwd["f_" + var]))
-        else:
+        if not hasattr(gcm, "set_profile_tendencies"):
             for i, gi in enumerate(les_models.grid_indices):
                 for var in ("U", "V", "T", "SH", "QL", "QI", "A"):
                     gcm.set_profile_tendency(var, gi, _wrap("f_" + var, batch.bwd["f_" + var][i].copy()))
@@ -1044,6 +1064,7 @@ def write_les_profiles_batched(les_models):
                          "THL": m.get_profile_THL(), "QT": m.get_profile_QT(), "QL": m.get_profile_QL(),
                          "QL_ice": m.get_profile_QL_ice(), "QR": m.get_profile_QR(), "T": m.get_profile_T()}
         prof = batch.stack_profiles(keys, src)
+    _inputs_ready(batch)
     d = batch.engine.diagnostics(batch.gcm, batch.zf, prof)                                  # K5: t, ql_water
     h = _to_host
     out = dict(u=h(prof["U"]), v=h(prof["V"]), presf=h(prof["presf"]), qt=h(prof["QT"]), ql=h(prof["QL"]),

@@ -32,6 +32,7 @@ class Arena:
             self.hn[name] = self.h[name].numpy()
             self.begin[name], self.end[name] = o, o + nb
         self.done = None        # event of the last download (created on first use)
+        self.side, self.pushed, self.landed, self.pending = None, False, {}, {}
 
     def upload(self, upto=None, what="h2d"):
         """host -> device (one async copy on the current stream; later kernels on that stream are ordered after it)"""
@@ -58,6 +59,66 @@ class Arena:
                 self.done = torch.cuda.Event()
             self.done.record(torch.cuda.current_stream(self.device))
             self.done.synchronize()
+
+
+    # ---- piecewise transfers on a copy stream of the arena's own: overlapped with the host's model calls ----------------
+    def _side(self):
+        if self.side is None:
+            self.side = torch.cuda.Stream(self.device)
+        return self.side
+
+    def push(self, name, what="h2d"):
+        """host -> device of ONE array, asynchronously on the arena's copy stream: the caller goes on filling the next
+        array (a model getter) while this one is on the wire.  The compute stream picks the data up with ``fence()``."""
+        if self.dev is self.host:
+            return
+        o, n = self.begin[name], self.end[name]
+        with torch.cuda.stream(self._side()):
+            if trace is not None:
+                with trace.region(what, n - o, self.device):
+                    self.dev[o:n].copy_(self.host[o:n], non_blocking=True)
+            else:
+                self.dev[o:n].copy_(self.host[o:n], non_blocking=True)
+        self.pushed = True
+
+    def fence(self):
+        """the CURRENT stream waits for every ``push()`` issued so far (call before launching the kernel that reads them)"""
+        if self.dev is not self.host and self.pushed:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+            self.pushed = False
+
+    def pull(self, names, what="d2h"):
+        """device -> host of the named arrays, one after the other on the copy stream, each followed by an event of its
+        own (``ready(name)`` waits for it): the host hands the first array to a model setter while the next ones are still
+        on the wire.  The copy stream first waits for what the current stream has been given so far (the producing kernel)."""
+        if self.dev is self.host:
+            return
+        side = self._side()
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for name in names:
+                o, n = self.begin[name], self.end[name]
+                if trace is not None:
+                    with trace.region(what, n - o, self.device):
+                        self.host[o:n].copy_(self.dev[o:n], non_blocking=True)
+                else:
+                    self.host[o:n].copy_(self.dev[o:n], non_blocking=True)
+                ev = self.landed.get(name)
+                if ev is None:
+                    ev = self.landed[name] = torch.cuda.Event()
+                ev.record(side)
+                self.pending[name] = ev
+
+    def ready(self, name=None):
+        """wait until the pulled array ``name`` (default: every pulled array) is in host memory"""
+        if name is None:
+            for ev in self.pending.values():
+                ev.synchronize()
+            self.pending.clear()
+        else:
+            ev = self.pending.pop(name, None)
+            if ev is not None:
+                ev.synchronize()
 
 
 class StepTrace:
@@ -181,6 +242,7 @@ class ShardedArena:
             self.begin[name], self.end[name] = o, o + nb
             self.order.append(name)
         self.done = [None] * len(self.devices)
+        self.pending = {}
 
     def _on(self, di):
         """context in which device di's copies are issued: its device, and its own stream if it has one"""
@@ -220,6 +282,34 @@ class ShardedArena:
                     self.done[di].record(torch.cuda.current_stream(dev))
         for ev in self.done:
             if ev is not None:
+                ev.synchronize()
+
+
+    # ---- piecewise transfers (as Arena's): every device's copies go on that device's own stream, so there is nothing to
+    #      fence; an array is ready when every device's piece of it has landed
+    def push(self, name, what="h2d"):
+        self.upload(upto=name, start=name, what=what)
+
+    def fence(self):
+        pass
+
+    def pull(self, names, what="d2h"):
+        for di, dev in enumerate(self.devices):
+            lo, hi = self.bounds[di], self.bounds[di + 1]
+            if hi == lo:
+                continue
+            with self._on(di):
+                for name in names:
+                    self.h[name][lo:hi].copy_(self.d[name].parts[di], non_blocking=True)
+                    if dev.type == "cuda":
+                        ev = torch.cuda.Event()
+                        ev.record(torch.cuda.current_stream(dev))
+                        self.pending.setdefault(name, []).append(ev)
+
+    def ready(self, name=None):
+        names = list(self.pending) if name is None else [name]
+        for nm in names:
+            for ev in self.pending.pop(nm, ()):
                 ev.synchronize()
 
 

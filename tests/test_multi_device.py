@@ -150,21 +150,21 @@ def test_multi_device_exchange_plans_equal_the_single_engine_plans_bitwise():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("batched,cplsurf", [(True, True), (False, False)])
-def test_one_gpu_pipelined_over_streams_equals_the_plain_engine(batched, cplsurf):
-    """multi.streamed_engine: chunks of the batch on streams of their own (upload of chunk c + 1 overlapping kernel and
-    download of chunk c) -- what spcpl.get_engine() gives a one-GPU process for large batches -- against a plain Engine"""
+def test_engines_with_streams_of_their_own_on_one_gpu():
+    """each engine of a MultiDeviceEngine may carry its own stream (Engine(stream=...)): chunks of one batch then run on
+    different streams of one GPU; same bits as the plain engine"""
+    import torch
     from sp_coupler_amd.engine import Engine
-    from sp_coupler_amd.multi import streamed_engine
-    ref = _closed_loop(Engine("cuda:0"), 900, 3, batched, cplsurf, nG=91, nL=160)
-    st = streamed_engine("cuda:0", n_streams=3, min_cols_per_chunk=200)
-    assert st.devices_for(900) == 3 and [e.stream is None for e in st.engines] == [True, False, False]
-    got = _closed_loop(st, 900, 3, batched, cplsurf, nG=91, nL=160)
+    ref = _closed_loop(Engine("cuda:0"), 900, 3, True, True, nG=91, nL=160)
+    dev = torch.device("cuda:0")
+    st = MultiDeviceEngine([Engine(dev), Engine(dev, stream=torch.cuda.Stream(dev)), Engine(dev, stream=torch.cuda.Stream(dev))],
+                           min_cols_per_device=200)
+    got = _closed_loop(st, 900, 3, True, True, nG=91, nL=160)
     for var in ref[0]:
         assert numpy.array_equal(ref[0][var], got[0][var], equal_nan=True), var
     assert numpy.array_equal(ref[2], got[2]) and got[3] == ("ShardedArena", ["MultiPlan"])
     # a batch below the threshold stays in one piece on the first engine: plain arenas, plain plans
-    small = _closed_loop(streamed_engine("cuda:0", n_streams=4), 300, 2, batched, cplsurf, nG=91, nL=160)
+    small = _closed_loop(MultiDeviceEngine([Engine(dev), Engine(dev)]), 300, 2, True, True, nG=91, nL=160)
     assert small[3][0] == "Arena" and "MultiPlan" not in small[3][1]
 
 

@@ -13,6 +13,7 @@ class Arena:
     kernels need aligned bases).  With a CPU "device" (the test-only oracle engine) host and device are one buffer."""
 
     ALIGN = 256
+    PIECE_MIN = 4 << 20          # arrays smaller than this travel together in one copy, larger ones each on their own
 
     def __init__(self, device, specs):
         self.device = torch.device(device)
@@ -32,7 +33,7 @@ class Arena:
             self.hn[name] = self.h[name].numpy()
             self.begin[name], self.end[name] = o, o + nb
         self.done = None        # event of the last download (created on first use)
-        self.side, self.pushed, self.landed, self.pending = None, False, {}, {}
+        self.side, self.pushed, self.landed, self.pending, self.deferred, self.deferred_what = None, False, {}, {}, None, "h2d"
 
     def upload(self, upto=None, what="h2d"):
         """host -> device (one async copy on the current stream; later kernels on that stream are ordered after it)"""
@@ -73,6 +74,10 @@ class Arena:
         if self.dev is self.host:
             return
         o, n = self.begin[name], self.end[name]
+        if n - o < self.PIECE_MIN:                  # small arrays: collected, sent as ONE copy at fence() (a copy of ~1 MB
+            lo, hi = self.deferred or (o, n)        # reaches half the PCIe rate of a large one: overlap would not pay)
+            self.deferred, self.deferred_what = (min(lo, o), max(hi, n)), what
+            return
         with torch.cuda.stream(self._side()):
             if trace is not None:
                 with trace.region(what, n - o, self.device):
@@ -83,7 +88,17 @@ class Arena:
 
     def fence(self):
         """the CURRENT stream waits for every ``push()`` issued so far (call before launching the kernel that reads them)"""
-        if self.dev is not self.host and self.pushed:
+        if self.dev is self.host:
+            return
+        if self.deferred is not None:
+            lo, hi = self.deferred
+            self.deferred = None
+            if trace is not None:
+                with trace.region(self.deferred_what, hi - lo, self.device):
+                    self.dev[lo:hi].copy_(self.host[lo:hi], non_blocking=True)
+            else:
+                self.dev[lo:hi].copy_(self.host[lo:hi], non_blocking=True)
+        if self.pushed:
             torch.cuda.current_stream(self.device).wait_stream(self.side)
             self.pushed = False
 
@@ -95,6 +110,21 @@ class Arena:
             return
         side = self._side()
         side.wait_stream(torch.cuda.current_stream(self.device))
+        if all(self.end[nm] - self.begin[nm] < self.PIECE_MIN for nm in names):     # small: ONE copy of the covering range
+            lo, hi = min(self.begin[nm] for nm in names), max(self.end[nm] for nm in names)
+            with torch.cuda.stream(side):
+                if trace is not None:
+                    with trace.region(what, hi - lo, self.device):
+                        self.host[lo:hi].copy_(self.dev[lo:hi], non_blocking=True)
+                else:
+                    self.host[lo:hi].copy_(self.dev[lo:hi], non_blocking=True)
+                ev = self.landed.get("*")
+                if ev is None:
+                    ev = self.landed["*"] = torch.cuda.Event()
+                ev.record(side)
+            for nm in names:
+                self.pending[nm] = ev
+            return
         with torch.cuda.stream(side):
             for name in names:
                 o, n = self.begin[name], self.end[name]

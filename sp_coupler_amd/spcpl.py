@@ -145,6 +145,10 @@ class StepBuffers:
                              + [(k, (n, nL), dt) for k in ("u", "v", "thl", "qt")] + [("ps", (n,), dt)], rows=n)
         self.bwd_out = engine.arena([(k, (n, nG), dt) for k in ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A")]
                                     + [("start_index", (n,), _I32)], rows=n)
+        # large batches: every array crosses PCIe on its own, overlapped with the model's next getter / setter call; small
+        # ones (arrays under transfer.Arena.PIECE_MIN): one call, one copy per group as before (the per-array calls and
+        # events would cost more host time than the overlap hides)
+        self.piecewise = n * nL * 8 >= transfer.Arena.PIECE_MIN
         self.plans = {}
         self.grid_key = None
         self.zf = self.zh = self.zf_host = self.zh_host = None
@@ -732,9 +736,14 @@ def _ensemble_forcings(ens, firststep, profiles, dt_gcm, factor, couple_surface,
         raise NotImplementedError("qt_forcing='variance' needs the 3-D LES fields: an ensemble must offer get_fields_batched / "
                                   "set_fields_batched (sp_coupler_amd.models docstring), or pass the LES objects as a plain list")
     if firststep:                                                            # spcpl.py:302-308, 321
-        for k in _FWD_KEYS:                     # variable by variable: each is on the wire while the next is fetched
-            ens.get_profiles_batched((k,), {k: hn[k]})
-            b.les_in.push(k, "h2d_les")
+        if b.piecewise:
+            for k in _FWD_KEYS:                 # variable by variable: each is on the wire while the next is fetched
+                ens.get_profiles_batched((k,), {k: hn[k]})
+                b.les_in.push(k, "h2d_les")
+        else:
+            ens.get_profiles_batched(_FWD_KEYS, {k: hn[k] for k in _FWD_KEYS})
+            for k in _FWD_KEYS:
+                b.les_in.push(k, "h2d_les")
         b.rain_prev = numpy.zeros(batch.n)                                   # `except: rain_last = 0`, spcpl.py:316-319
     elif profiles is None or profiles.get("_buffers") is not b:
         raise RuntimeError("set_les_forcings_batched: pass what get_les_profiles_batched() returned after the last "
@@ -743,10 +752,15 @@ def _ensemble_forcings(ens, firststep, profiles, dt_gcm, factor, couple_surface,
     host = forward_batched(batch, dev, dt_gcm, factor, couple_surface, wait=False)
     # the setters of spcpl.py:341-347 in their order, each as soon as ITS array has landed: the model takes f_u while
     # f_v ... are still crossing PCIe
-    for key, name in (("U", "f_u"), ("V", "f_v"), ("THL", "f_thl"), ("QT", "f_qt"), ("SP", "f_ps"), ("QL", "f_ql"), ("QLp", "ql_ref")):
-        b.fwd_out.ready(name)
-        ens.set_forcings_batched(**{key: host[name]})
-    b.fwd_out.ready()
+    pairs = (("U", "f_u"), ("V", "f_v"), ("THL", "f_thl"), ("QT", "f_qt"), ("SP", "f_ps"), ("QL", "f_ql"), ("QLp", "ql_ref"))
+    if b.piecewise:
+        for key, name in pairs:
+            b.fwd_out.ready(name)
+            ens.set_forcings_batched(**{key: host[name]})
+        b.fwd_out.ready()
+    else:
+        b.fwd_out.ready()
+        ens.set_forcings_batched(**{key: host[name] for key, name in pairs})
     if couple_surface:                                                       # spcpl.py:359-364
         ens.set_forcings_batched(Z0M_surf=host["z0m"], Z0H_surf=host["z0h"], WT_surf=host["wthl"], WQ_surf=host["wqt"])
     _finish_forward(batch, host, hn["Rain"], getattr(b, "rain_prev", numpy.zeros(batch.n)), dt_gcm)
@@ -873,9 +887,14 @@ def get_les_profiles_batched(les_models, asynchronous=False, diagnostics=False):
     b = batch.buf
     hn = b.les_in.hn
     keys = _LES_IN_LEVELS + ("PS", "Rain") + (_LES_DIAG_LEVELS if diagnostics else ())
-    for k in keys:                              # variable by variable: each is on the wire while the next is fetched
-        ens.get_profiles_batched((k,), {k: hn[k]})
-        b.les_in.push(k, "h2d_les")
+    if b.piecewise:
+        for k in keys:                          # variable by variable: each is on the wire while the next is fetched
+            ens.get_profiles_batched((k,), {k: hn[k]})
+            b.les_in.push(k, "h2d_les")
+    else:
+        ens.get_profiles_batched(keys, {k: hn[k] for k in keys})
+        for k in keys:
+            b.les_in.push(k, "h2d_les")
     ens.get_cloudfraction_batched(_index_map(batch), hn["A"])                 # spcpl.py:761-765
     b.les_in.push("A", "h2d_les")
     batch.profile_generation += 1
@@ -995,6 +1014,8 @@ def set_gcm_tendencies_batched(gcm, les_models, profiles, dt_gcm, factor=1, writ
         if (write and writer is not None or conservative) and "Rhobf" not in profiles:
             raise RuntimeError("conservative coarsening / spifs output need get_les_profiles_batched(diagnostics=True)")
         batch.bwd = backward_batched(batch, b.les_in.d, dt_gcm, factor, conservative, wait=False)
+        if not b.piecewise:
+            b.bwd_out.ready()
         if hasattr(gcm, "set_profile_tendencies"):
             for var in _TEND_VARS:                                               # spcpl.py:535-542, each as it lands
                 b.bwd_out.ready("f_" + var)

@@ -250,6 +250,8 @@ class ColumnBatch:
         self.row = None if self.ens is not None else {id(les): i for i, les in enumerate(self.les_models)}
         self.extra_cols = list(extra_cols)
         self.cols = list(cols)
+        self.cols_arr = numpy.asarray(self.cols)          # what the GCM getters are handed (an index array, not a list)
+        self.gi_ref = self.ens.grid_indices if self.ens is not None else None
         self.couple_surface = bool(couple_surface)
         n_total = len(cols)
         self.use_out = bool(getattr(gcm, "supports_out", False))
@@ -291,7 +293,7 @@ class ColumnBatch:
         """one ``get_profile_fields`` per variable straight into the pinned buffer; each variable starts crossing PCIe on
         the buffer's copy stream as soon as it is there, overlapped with the fetch of the next one (spcpl.py:62-75)"""
         arena = self.buf.gcm_in
-        hn, cols, use_out = arena.hn, self.cols, self.use_out
+        hn, cols, use_out = arena.hn, self.cols_arr, self.use_out
         for v in gcm_vars:                                                    # spcpl.py:62-67
             if v == gcm_vars[0] and first is not None:
                 numpy.copyto(hn[v], first)
@@ -440,14 +442,19 @@ def gather_gcm_data(gcm, les_models, couple_surface, output_column_indices=None,
     global _current
     extra_cols = [] if output_column_indices is None else list(output_column_indices)
     ens = les_models if _is_ensemble(les_models) else None
-    cols = (list(ens.grid_indices) if ens is not None else [les.grid_index for les in les_models]) + extra_cols
     start = time.time()
+    eng = get_engine()
+    prev = _current
+    if (ens is not None and prev is not None and prev.ens is ens and prev.gi_ref is ens.grid_indices and prev.engine is eng
+            and prev.extra_cols == extra_cols and prev.couple_surface == bool(couple_surface)
+            and _buffers.get(prev.buf.key) is prev.buf):
+        cols = prev.cols                     # the same ensemble object as last step: nothing to rebuild or compare
+    else:
+        cols = ([int(g) for g in ens.grid_indices] if ens is not None else [les.grid_index for les in les_models]) + extra_cols
     if not any(cols):                                                        # quirk kept: spcpl.py:63,71
         _current = None
         return None
-    eng = get_engine()
-    prev = _current
-    if prev is not None and prev.reusable_for(eng, les_models, cols, couple_surface):
+    if prev is not None and (cols is prev.cols or prev.reusable_for(eng, les_models, cols, couple_surface)):
         batch = prev                                     # same columns as last step: handles stay, buffers are refilled
         batch.refill(gcm)
         if attach_rows and batch.ens is None:

@@ -186,18 +186,24 @@ def dropin_rate(eng, n_les=1024, steps=30, warmup=5, per_les_steps=5):
            "note": "wall time of Coupler.step minus time inside model methods; includes H2D/D2H of every step"}
     gcm, ens = models.make_batched_models(n_les, nG=91, nL=160, seed=3)
     cpl = Coupler(gcm, ens)
-    for _ in range(warmup):
+    import gc
+    gc.collect()                             # the big workloads above have just been dropped: not inside the timed passes
+    for _ in range(2 * warmup):
         cpl.step()
-    torch.cuda.synchronize()
-    models.model_seconds = 0.0
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        cpl.step()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    out["batched_protocol"] = {"value": n_les * steps / (wall - models.model_seconds), "steps": steps,
-                               "ms_per_step_coupler": (wall - models.model_seconds) / steps * 1e3,
-                               "ms_per_step_models": models.model_seconds / steps * 1e3}
+    passes = []
+    for _ in range(3):                       # three passes of `steps` steps; the median is reported, all three are listed
+        torch.cuda.synchronize()
+        models.model_seconds = 0.0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            cpl.step()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        passes.append(((wall - models.model_seconds) / steps * 1e3, models.model_seconds / steps * 1e3))
+    ms_c, ms_m = sorted(passes)[1]
+    out["batched_protocol"] = {"value": n_les / (ms_c * 1e-3), "steps": steps, "passes": 3,
+                               "ms_per_step_coupler": ms_c, "ms_per_step_models": ms_m,
+                               "ms_per_step_coupler_all_passes": [p_[0] for p_ in passes]}
     # the same steps again with HIP events around every copy / launch (the events cost a little host time themselves)
     transfer.trace = tr = transfer.StepTrace()
     models.model_seconds = 0.0

@@ -945,6 +945,9 @@ template <typename KernelT> int pick_cb(const spc_dims *d, int pass, bool with_i
         nb[i] = blocks_per_cu(kernel, smem);
         if (cb <= 4 && (d->n_cols + cb - 1) / cb <= (int64_t)256 * nb[i]) return cb;   // rule 1
     }
+    // K4 is bound by dependent LDS reads, not by memory: what counts is resident COLUMNS (2 x 4 workgroups beat 1 x 5
+    // by 11 % at config 3, 4 x 2 loses 60 %: profiles/r03_k4_forms.log)
+    if (pass == 4 && nb[1] * 2 > nb[0] && (d->n_cols + 1) / 2 >= (int64_t)2 * 256 * nb[1]) return 2;
     int best = 1, best_nb = -1;
     for (int i = 3; i >= 0; --i) {                                                      // rule 2
         cb = 1 << i;

@@ -9,6 +9,13 @@
 // evaluation.  LDS per column: q[7][nL+1] = t | qt | ql | ql_ice | u | v | rho (one element of padding per
 // field: a field stride of nL x 8 B = 0 mod 64 banks would put the eight lanes of a level on one bank), then
 // Zf[nG] | Zh[nG+1] | X[7][nG] (layer means) | cell range ia, ib and edge pieces da, db per level [4][nG]; then zf and zh ([nL] each when shared, else [CB x nL] each).
+// Round 3 built and measured four other forms of this kernel at config 3 (profiles/r03_k4_forms.log), all SLOWER than
+// this one with two columns per workgroup (223 us): a compacted list of the (column, level) pairs that have cells
+// (255 us); one thread per (tendency, level) with the level running fastest, every thread repeating the weight sum,
+// no layer means in LDS (366 us); the eight lanes of a level storing their own tendency -- 64-byte segments per array,
+// one phase and 5 KB of LDS less (259-282 us); and this form on 15.6 instead of 19 KB of LDS per column (edge pieces
+// recomputed, Zf overlaid, zf not staged), which costs 6 VGPRs and with them the fifth wave per SIMD (232 us; 276 us
+// when the fifth wave is bought with spills).  K4 is bound by the dependent LDS reads of its searches and sums.
 #pragma once
 
 // numpy's pairwise recursion with its depth fixed at compile time (no stack, no scratch memory): for the compile-time

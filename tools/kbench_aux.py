@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--levels", default="91,160")
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--vn-cols", default="2,64")
+    ap.add_argument("--k4-cbs", default="0", help="cols_per_block settings for K4 (0 = the library's choice)")
     ap.add_argument("--vn-shapes", default="64x64x160", help="LES field extents itot x jtot x ktot, comma separated")
     ap.add_argument("--vn-modes", default="default", help="default (LDS / streamed planes), sweep (SPC_VN_LDS=0: the sweeping kernel)")
     ap.add_argument("--vn-iters", type=int, default=20)
@@ -50,9 +51,12 @@ def main():
         p = {k: torch.from_numpy(v).cuda() for k, v in prof.items()}
         zf_d, zh_d = torch.from_numpy(zf).cuda(), torch.from_numpy(zh).cuda()
         k3 = eng.plan_backward(g, zf_d, p, 1.0, 900.0, Zf=None, want_start_index=False)
-        k4 = eng.plan_backward(g, zf_d, p, 1.0, 900.0, Zf=None, want_start_index=False, conservative=True, zh=zh_d)
         t3 = timed(lambda: k3.launch_raw(sptr), a.iters)
-        t4 = timed(lambda: k4.launch_raw(sptr), a.iters)
+        for cb in (int(x) for x in a.k4_cbs.split(",")):
+            k4 = eng.plan_backward(g, zf_d, p, 1.0, 900.0, Zf=None, want_start_index=False, conservative=True, zh=zh_d, cols_per_block=cb)
+            t4 = timed(lambda: k4.launch_raw(sptr), a.iters)
+            if cb:
+                print("n=%d K4 cols_per_block=%d: %.1f us (%.2fx K3)" % (n, cb, t4, t4 / t3), flush=True)
         b3 = n * ((9 * nG + 6 * nL) + 7 * nG) * 8
         b4 = b3 + n * (nL + nG + 1) * 8                      # + Rhobf [nL], Zghalf [nG+1] per column
         t5a = timed(lambda: eng.diagnostics(g), a.iters)

@@ -513,9 +513,12 @@ def _plan(batch, kind, flags, make):
 
 
 def _inputs_ready(batch):
-    """the current stream waits for the uploads still in flight on the transfer buffers' copy streams"""
+    """the current stream waits for the uploads still in flight on the transfer buffers' copy streams (and for downloads
+    of the result buffers nobody has waited for: the next kernel overwrites them)"""
     batch.buf.gcm_in.fence()
     batch.buf.les_in.fence()
+    batch.buf.fwd_out.settle()
+    batch.buf.bwd_out.settle()
 
 
 def _launch(batch, plan, what):

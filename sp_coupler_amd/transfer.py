@@ -78,7 +78,10 @@ class Arena:
             lo, hi = self.deferred or (o, n)        # reaches half the PCIe rate of a large one: overlap would not pay)
             self.deferred, self.deferred_what = (min(lo, o), max(hi, n)), what
             return
-        with torch.cuda.stream(self._side()):
+        side = self._side()
+        if not self.pushed:      # first push since the last fence(): a kernel launched earlier on the compute stream may still
+            side.wait_stream(torch.cuda.current_stream(self.device))     # be reading this buffer (write-after-read)
+        with torch.cuda.stream(side):
             if trace is not None:
                 with trace.region(what, n - o, self.device):
                     self.dev[o:n].copy_(self.host[o:n], non_blocking=True)
@@ -101,6 +104,12 @@ class Arena:
         if self.pushed:
             torch.cuda.current_stream(self.device).wait_stream(self.side)
             self.pushed = False
+
+    def settle(self):
+        """the CURRENT stream waits for pulls nobody has waited for yet (call before launching a kernel that overwrites
+        this buffer on the device); free when every pull has been taken with ``ready()``, the normal case"""
+        if self.dev is not self.host and self.pending:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
 
     def pull(self, names, what="d2h"):
         """device -> host of the named arrays, one after the other on the copy stream, each followed by an event of its
@@ -321,6 +330,9 @@ class ShardedArena:
         self.upload(upto=name, start=name, what=what)
 
     def fence(self):
+        pass
+
+    def settle(self):
         pass
 
     def pull(self, names, what="d2h"):

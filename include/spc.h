@@ -20,6 +20,9 @@
  *   spc_variability_nudge_f64 <- spcpl.variability_nudge  splib/spcpl.py:613-744 (qt_forcing == 'variance')
  *   spc_diagnostics_*    <- spifs.nc diagnostics          splib/spcpl.py:176,214-215,408-409;
  *                           spcpl.output_column_conversion splib/spcpl.py:251-267
+ *   spc_exner_* / spc_interp_* / spc_searchsorted_* / spc_interp_c_* / spc_rms_*
+ *                        <- the helpers of splib/sputils.py on their own (exner, iexner :28-34; interp :82-86;
+ *                           searchsorted :88-91; integral, interp_c, interp_rho :94-197; rms :23-24), batched over rows
  *
  * Conventions
  *   - All data pointers are DEVICE pointers (HBM) owned by the caller; the library never allocates,
@@ -46,7 +49,7 @@
 extern "C" {
 #endif
 
-#define SPC_ABI_VERSION 3
+#define SPC_ABI_VERSION 4
 
 typedef enum spc_status {
     SPC_OK = 0,
@@ -191,6 +194,74 @@ typedef struct spc_vnudge_args {
 } spc_vnudge_args;
 
 int spc_variability_nudge_f64(const spc_vnudge_args *args, void *stream);
+
+/* ---- the helpers of splib/sputils.py as standalone batched operators (kernel family K7) ---------------------- */
+/* The fused kernels above contain this arithmetic already; these entry points serve callers that use a helper on its
+ * own (sp_coupler_amd/sputils.py keeps the reference's names on top of them).  A "row" is one independent 1-D problem
+ * (one column); arrays are [n_rows x n] with an element pitch between rows; where stated a pitch of 0 means ONE row
+ * shared by all rows (the LES grid).  Results are bit-identical to NumPy for interp / searchsorted / integral /
+ * interp_c / interp_rho / rms; exner / iexner agree with numpy.power to <= 2 ulp.                                  */
+
+/* sputils.exner (inverse == 0) / iexner (inverse != 0), splib/sputils.py:28-34: out[i] = (p[i]/pref0)**(+-rd/cp)   */
+int spc_exner_f64(int64_t n, const void *p, void *out, int32_t inverse, void *stream);
+int spc_exner_f32(int64_t n, const void *p, void *out, int32_t inverse, void *stream);
+
+/* sputils.interp, splib/sputils.py:82-86 == numpy.interp(x, xp, fp) per row (end-clamped, exact-hit shortcut, NaN
+ * fallbacks; xp increasing; no left / right / period).  n_xp == 0 is refused as numpy does (ValueError).            */
+typedef struct spc_interp_args {
+    int64_t n_rows;
+    int32_t n_x, n_xp;
+    int64_t pitch_x, pitch_xp;     /* 0 = shared by all rows */
+    int64_t pitch_fp, pitch_out;
+    const void *x;                 /* [n_rows x n_x]  points to evaluate at   */
+    const void *xp, *fp;           /* [n_rows x n_xp] sample points / values  */
+    void *out;                     /* [n_rows x n_x]                          */
+} spc_interp_args;
+int spc_interp_f64(const spc_interp_args *args, void *stream);
+int spc_interp_f32(const spc_interp_args *args, void *stream);
+
+/* sputils.searchsorted, splib/sputils.py:88-91 == numpy.searchsorted(a, v, side) per row; NaN sorts to the end.    */
+typedef struct spc_searchsorted_args {
+    int64_t n_rows;
+    int32_t n_a, n_v;
+    int64_t pitch_a, pitch_v;      /* 0 = shared by all rows */
+    int64_t pitch_out;
+    const void *a;                 /* [n_rows x n_a] sorted ascending */
+    const void *v;                 /* [n_rows x n_v]                  */
+    int64_t *out;                  /* [n_rows x n_v] insertion indices (numpy's intp) */
+    int32_t side_right;            /* 0: side='left', 1: side='right' */
+    int32_t reserved;
+} spc_searchsorted_args;
+int spc_searchsorted_f64(const spc_searchsorted_args *args, void *stream);
+int spc_searchsorted_f32(const spc_searchsorted_args *args, void *stream);
+
+/* sputils.integral / interp_c / interp_rho, splib/sputils.py:94-197.  Per row: Zh [nG+1] coarse layer bounds
+ * (descending in the reference's use), zh [nL] fine grid points (ascending; they bound nL-1 cells), q [>= nL-1] cell
+ * values, rho cell weights.
+ *   mode 0 interp_c  : out[k] = integral(Zh[k+1], Zh[k], zh, q, rho) where Zh[k] < zh[nL-1], else 0 (sputils.py:185-188)
+ *   mode 1 interp_rho: out[k] = integral(Zh[k+1], Zh[k], zh, q) / (Zh[k] - Zh[k+1]) where Zh[k] < zh[nL-1], else 0
+ *                      (sputils.py:191-197; q is the density, rho is ignored)
+ *   mode 2 integral  : out[k] = integral(Zh[k+1], Zh[k], zh, q, rho or NULL), no test against the top
+ * Where integral() returns None (an end point outside zh) the output is NaN (what Q[i] = None stores).  Sums in
+ * numpy's ndarray.sum() order.                                                                                      */
+typedef struct spc_interp_c_args {
+    int64_t n_rows;
+    int32_t nG, nL;
+    int64_t pitch_Zh;
+    int64_t pitch_zh;              /* 0 = shared by all rows */
+    int64_t pitch_q;               /* of q and rho           */
+    int64_t pitch_out;
+    const void *Zh, *zh, *q, *rho;
+    void *out;                     /* [n_rows x nG]          */
+    int32_t mode;
+    int32_t reserved;
+} spc_interp_c_args;
+int spc_interp_c_f64(const spc_interp_c_args *args, void *stream);
+int spc_interp_c_f32(const spc_interp_c_args *args, void *stream);
+
+/* sputils.rms, splib/sputils.py:23-24: out[r] = sqrt(mean(a[r]**2)), the mean in numpy's pairwise order             */
+int spc_rms_f64(int64_t n_rows, int64_t n, int64_t pitch, const void *a, void *out, void *stream);
+int spc_rms_f32(int64_t n_rows, int64_t n, int64_t pitch, const void *a, void *out, void *stream);
 
 /* ---- misc ----------------------------------------------------------------------------------- */
 int spc_abi_version(void);          /* == SPC_ABI_VERSION                                          */

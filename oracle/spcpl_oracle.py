@@ -140,6 +140,15 @@ def interp_c(Zh, zh, q, rho):
     return Q
 
 
+def interp_rho(Zh, zh, rho):
+    """splib/sputils.py:191-197 -- a density on the coarser grid (unweighted integral / layer thickness)."""
+    RHO = numpy.zeros(len(Zh) - 1)
+    for i in range(len(RHO)):
+        if Zh[i] < zh[-1]:
+            RHO[i] = integral(Zh[i + 1], Zh[i], zh, rho) / (Zh[i] - Zh[i + 1])
+    return RHO
+
+
 def cloud_fraction_indices(zh, Zh):
     """splib/spcpl.py:26 and 764: searchsorted(zh, Zh, side='right')[:-1][::-1]"""
     return searchsorted(zh, Zh, side="right")[:-1:][::-1]

@@ -6,7 +6,7 @@ The product path has NO CPU fallback: ``load_library()`` raises ``SpcLibraryErro
 import ctypes
 import os
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libspc_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
@@ -70,6 +70,22 @@ class VnudgeArgs(ctypes.Structure):
                 + [("work_bytes", c_int64)])
 
 
+class InterpArgs(ctypes.Structure):
+    _fields_ = ([("n_rows", c_int64), ("n_x", c_int32), ("n_xp", c_int32), ("pitch_x", c_int64), ("pitch_xp", c_int64),
+                 ("pitch_fp", c_int64), ("pitch_out", c_int64)] + _ptrs("x", "xp", "fp", "out"))
+
+
+class SearchsortedArgs(ctypes.Structure):
+    _fields_ = ([("n_rows", c_int64), ("n_a", c_int32), ("n_v", c_int32), ("pitch_a", c_int64), ("pitch_v", c_int64),
+                 ("pitch_out", c_int64)] + _ptrs("a", "v", "out") + [("side_right", c_int32), ("reserved", c_int32)])
+
+
+class InterpCArgs(ctypes.Structure):
+    _fields_ = ([("n_rows", c_int64), ("nG", c_int32), ("nL", c_int32), ("pitch_Zh", c_int64), ("pitch_zh", c_int64),
+                 ("pitch_q", c_int64), ("pitch_out", c_int64)] + _ptrs("Zh", "zh", "q", "rho", "out")
+                + [("mode", c_int32), ("reserved", c_int32)])
+
+
 #: every symbol include/spc.h declares: name -> (restype, argtypes)
 PROTOTYPES = {
     "spc_forward_f64": (ctypes.c_int, [ctypes.POINTER(Dims), ctypes.POINTER(ForwardArgs), c_void_p]),
@@ -83,6 +99,16 @@ PROTOTYPES = {
     "spc_surface_fluxes_f64": (ctypes.c_int, [c_int64] + [c_void_p] * 9),
     "spc_surface_fluxes_f32": (ctypes.c_int, [c_int64] + [c_void_p] * 9),
     "spc_variability_nudge_f64": (ctypes.c_int, [ctypes.POINTER(VnudgeArgs), c_void_p]),
+    "spc_exner_f64": (ctypes.c_int, [c_int64, c_void_p, c_void_p, c_int32, c_void_p]),
+    "spc_exner_f32": (ctypes.c_int, [c_int64, c_void_p, c_void_p, c_int32, c_void_p]),
+    "spc_interp_f64": (ctypes.c_int, [ctypes.POINTER(InterpArgs), c_void_p]),
+    "spc_interp_f32": (ctypes.c_int, [ctypes.POINTER(InterpArgs), c_void_p]),
+    "spc_searchsorted_f64": (ctypes.c_int, [ctypes.POINTER(SearchsortedArgs), c_void_p]),
+    "spc_searchsorted_f32": (ctypes.c_int, [ctypes.POINTER(SearchsortedArgs), c_void_p]),
+    "spc_interp_c_f64": (ctypes.c_int, [ctypes.POINTER(InterpCArgs), c_void_p]),
+    "spc_interp_c_f32": (ctypes.c_int, [ctypes.POINTER(InterpCArgs), c_void_p]),
+    "spc_rms_f64": (ctypes.c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "spc_rms_f32": (ctypes.c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "spc_abi_version": (ctypes.c_int, []),
     "spc_last_error": (ctypes.c_char_p, []),
     "spc_device_count": (ctypes.c_int, []),

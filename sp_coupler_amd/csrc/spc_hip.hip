@@ -800,6 +800,7 @@ template <typename T> __device__ __forceinline__ int scan_cell(const T *z, int n
 }
 
 #include "spc_k4.hpp"
+#include "spc_sputils.hpp"
 
 // =================================================================================================
 // K5 diagnostics: splib/spcpl.py:176, 197-198, 214-215 (GCM levels); 402, 408-409 (LES levels)
@@ -1332,6 +1333,8 @@ template <typename T> int describe_impl(const spc_dims *d, int pass, int flags, 
     }
 }
 
+#include "spc_sputils_host.hpp"
+
 }  // namespace
 
 extern "C" {
@@ -1357,6 +1360,17 @@ int spc_debug_set_stamps(void *buf)  // diagnostic build only
     return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : SPC_ERR_LAUNCH;
 }
 #endif
+
+int spc_exner_f64(int64_t n, const void *p, void *out, int32_t inv, void *s) { return exner_impl<double>(n, p, out, inv, s); }
+int spc_exner_f32(int64_t n, const void *p, void *out, int32_t inv, void *s) { return exner_impl<float>(n, p, out, inv, s); }
+int spc_interp_f64(const spc_interp_args *a, void *s) { return interp_impl<double>(a, s); }
+int spc_interp_f32(const spc_interp_args *a, void *s) { return interp_impl<float>(a, s); }
+int spc_searchsorted_f64(const spc_searchsorted_args *a, void *s) { return searchsorted_impl<double>(a, s); }
+int spc_searchsorted_f32(const spc_searchsorted_args *a, void *s) { return searchsorted_impl<float>(a, s); }
+int spc_interp_c_f64(const spc_interp_c_args *a, void *s) { return interp_c_impl<double>(a, s); }
+int spc_interp_c_f32(const spc_interp_c_args *a, void *s) { return interp_c_impl<float>(a, s); }
+int spc_rms_f64(int64_t nr, int64_t n, int64_t pitch, const void *a, void *out, void *s) { return rms_impl<double>(nr, n, pitch, a, out, s); }
+int spc_rms_f32(int64_t nr, int64_t n, int64_t pitch, const void *a, void *out, void *s) { return rms_impl<float>(nr, n, pitch, a, out, s); }
 
 int spc_surface_fluxes_f64(int64_t n, const void *Ph_s, const void *T_s, const void *QLflux, const void *QIflux,
                            const void *SHflux, const void *TSflux, void *wthl, void *wqt, void *stream)

@@ -455,6 +455,111 @@ class Engine:
         _abi.check(self.lib, rc)
         return res
 
+    # -- K7: the helpers of splib/sputils.py as batched operators (sp_coupler_amd/sputils.py keeps their names) -------
+    def _rows(self, name, t, n_rows=None, shared_ok=False):
+        """(tensor, data_ptr, pitch, n): a [n_rows x n] matrix contiguous along n (pitch = row stride), or -- where the
+        operator allows it -- ONE [n] row shared by all rows (pitch 0)"""
+        if not isinstance(t, torch.Tensor):
+            raise TypeError("%s must be a torch.Tensor, got %s" % (name, type(t).__name__))
+        if t.device != self.device or t.dtype != self.dtype:
+            raise ValueError("%s must be %s on %s (got %s on %s)" % (name, self.dtype, self.device, t.dtype, t.device))
+        if t.dim() == 1:
+            if not shared_ok and n_rows not in (None, 1):
+                raise ValueError("%s must have %d rows, got one" % (name, n_rows))
+            t = t.contiguous()
+            return t, t.data_ptr(), (0 if shared_ok and n_rows not in (None, 1) else max(1, t.shape[0])), int(t.shape[0])
+        if t.dim() != 2:
+            raise ValueError("%s must be [n] or [n_rows x n], got %s" % (name, tuple(t.shape)))
+        if n_rows is not None and t.shape[0] != n_rows:
+            raise ValueError("%s must have %d rows, got %d" % (name, n_rows, t.shape[0]))
+        if t.shape[1] > 1 and t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+            t = t.contiguous()
+        return t, t.data_ptr(), (int(t.stride(0)) if t.shape[0] > 1 else max(1, int(t.shape[1]))), int(t.shape[1])
+
+    def _call(self, fn, *args, stream=None):
+        with torch.cuda.device(self.device):
+            rc = fn(*args, _stream_ptr(stream if stream is not None else self.stream, self.device))
+        _abi.check(self.lib, rc)
+
+    def exner(self, p, inverse=False, stream=None):
+        """sputils.exner / iexner (splib/sputils.py:28-34), elementwise on a device tensor of any shape"""
+        if p.device != self.device or p.dtype != self.dtype:
+            raise ValueError("p must be %s on %s" % (self.dtype, self.device))
+        p = p.contiguous()
+        out = torch.empty_like(p)
+        self._call(getattr(self.lib, "spc_exner_" + _DTYPES[self.dtype]), p.numel(), p.data_ptr(), out.data_ptr(), 1 if inverse else 0,
+                   stream=stream)
+        return out
+
+    def interp(self, x, xp, fp, stream=None):
+        """sputils.interp == numpy.interp (splib/sputils.py:82-86) for every row: fp [n_rows x n_xp] (or [n_xp]), xp the
+        same shape or one shared [n_xp], x [n_rows x n_x] or one shared [n_x].  Returns [n_rows x n_x] ([n_x] when every
+        argument is 1-D)."""
+        one = fp.dim() == 1 and xp.dim() == 1 and x.dim() == 1
+        n_rows = max(int(t.shape[0]) if t.dim() == 2 else 1 for t in (x, xp, fp))
+        fp2 = fp.unsqueeze(0).expand(n_rows, -1).contiguous() if (fp.dim() == 1 and n_rows > 1) else fp
+        fp2, p_fp, pitch_fp, n_xp = self._rows("fp", fp2, n_rows)
+        xp2, p_xp, pitch_xp, n_xp2 = self._rows("xp", xp, n_rows, shared_ok=True)
+        x2, p_x, pitch_x, n_x = self._rows("x", x, n_rows, shared_ok=True)
+        if n_xp2 != n_xp:
+            raise ValueError("fp and xp are not of the same length")          # numpy.interp's message
+        out = self.empty(n_rows, n_x)
+        a = _abi.InterpArgs(n_rows, n_x, n_xp, pitch_x, pitch_xp, pitch_fp, max(1, n_x), p_x, p_xp, p_fp, out.data_ptr())
+        self._call(getattr(self.lib, "spc_interp_" + _DTYPES[self.dtype]), ctypes.byref(a), stream=stream)
+        return out[0] if one else out
+
+    def searchsorted(self, a, v, side="left", stream=None):
+        """sputils.searchsorted == numpy.searchsorted (splib/sputils.py:88-91) per row; int64 indices"""
+        if side not in ("left", "right"):
+            raise ValueError("side must be 'left' or 'right'")
+        one = a.dim() == 1 and v.dim() == 1
+        n_rows = max(int(t.shape[0]) if t.dim() == 2 else 1 for t in (a, v))
+        a2, p_a, pitch_a, n_a = self._rows("a", a, n_rows, shared_ok=True)
+        v2, p_v, pitch_v, n_v = self._rows("v", v, n_rows, shared_ok=True)
+        out = torch.empty(n_rows, n_v, dtype=torch.int64, device=self.device)
+        args = _abi.SearchsortedArgs(n_rows, n_a, n_v, pitch_a, pitch_v, max(1, n_v), p_a, p_v, out.data_ptr(), 1 if side == "right" else 0, 0)
+        self._call(getattr(self.lib, "spc_searchsorted_" + _DTYPES[self.dtype]), ctypes.byref(args), stream=stream)
+        return out[0] if one else out
+
+    def interp_c(self, Zh, zh, q, rho=None, mode="interp_c", stream=None):
+        """sputils.interp_c / interp_rho / integral (splib/sputils.py:94-197) per row: Zh [n_rows x (nG+1)] layer bounds, zh
+        [nL] (shared) or [n_rows x nL] grid points, q (and rho) [n_rows x nL'] with nL' >= nL - 1 cell values.
+        mode 'interp_c' (rho required), 'interp_rho' (q is the density), 'integral' (rho optional)."""
+        modes = {"interp_c": 0, "interp_rho": 1, "integral": 2}
+        if mode not in modes:
+            raise ValueError("mode must be one of %s" % sorted(modes))
+        one = Zh.dim() == 1 and q.dim() == 1
+        n_rows = max(int(t.shape[0]) if t.dim() == 2 else 1 for t in (Zh, q))
+        Zh2, p_Zh, pitch_Zh, nGh = self._rows("Zh", Zh, n_rows)
+        zh2, p_zh, pitch_zh, nL = self._rows("zh", zh, n_rows, shared_ok=True)
+        q2, p_q, pitch_q, nq = self._rows("q", q, n_rows)
+        if nq < nL - 1:
+            raise ValueError("q has %d values, the %d grid points of zh bound %d cells" % (nq, nL, nL - 1))
+        p_rho = None
+        if rho is not None and mode != "interp_rho":
+            rho2, p_rho, pitch_rho, nr = self._rows("rho", rho, n_rows)
+            if nr != nq:
+                raise ValueError("rho and q must have the same shape")
+            if n_rows > 1 and pitch_rho != pitch_q:            # the ABI has ONE pitch for q and rho
+                rho2, q2 = rho2.contiguous(), q2.contiguous()
+                p_rho, p_q, pitch_q = rho2.data_ptr(), q2.data_ptr(), max(1, nq)
+        elif mode == "interp_c":
+            raise ValueError("interp_c needs the weights rho")
+        nG = nGh - 1
+        out = self.empty(n_rows, max(nG, 0))
+        a = _abi.InterpCArgs(n_rows, nG, nL, pitch_Zh, pitch_zh, pitch_q, max(1, nG), p_Zh, p_zh, p_q, p_rho, out.data_ptr(), modes[mode], 0)
+        self._call(getattr(self.lib, "spc_interp_c_" + _DTYPES[self.dtype]), ctypes.byref(a), stream=stream)
+        return out[0] if one else out
+
+    def rms(self, a, stream=None):
+        """sputils.rms (splib/sputils.py:23-24) of every row of a [n_rows x n] tensor (of the one row of a 1-D tensor)"""
+        one = a.dim() == 1
+        a2, p_a, pitch, n = self._rows("a", a)
+        n_rows = 1 if one else int(a2.shape[0])
+        out = self.empty(n_rows)
+        self._call(getattr(self.lib, "spc_rms_" + _DTYPES[self.dtype]), n_rows, n, max(pitch, n), p_a, out.data_ptr(), stream=stream)
+        return out[0] if one else out
+
     # -- surface fluxes of columns without an LES -------------------------------------------------
     def plan_surface_fluxes(self, Ph_s, T_s, QLflux, QIflux, SHflux, TSflux, out=None):
         """(wthl, wqt) of spcpl.convert_surface_fluxes (splib/spcpl.py:153-161) for [n] scalars."""

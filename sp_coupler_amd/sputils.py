@@ -1,0 +1,163 @@
+"""The helpers of ``splib/sputils.py`` on the GPU, under the reference's names.
+
+``exner``, ``iexner`` (sputils.py:28-34), ``interp`` (:82-86), ``searchsorted`` (:88-91), ``integral`` (:94-161),
+``interp_c`` (:173-189), ``interp_rho`` (:191-197) and ``rms`` (:23-24) take what the reference's functions take -- one
+column as 1-D arrays (NumPy, or AMUSE quantities: ``.number`` is used, every unit of this path is SI-coherent) -- and,
+beyond the reference, whole batches ``[n_cols x n_lev]`` in one call.  The arithmetic runs in the K7 kernels of
+``libspc_hip.so`` (``include/spc.h``: ``spc_exner_*``, ``spc_interp_*``, ``spc_searchsorted_*``, ``spc_interp_c_*``,
+``spc_rms_*``) on the engine of ``spcpl.get_engine()``; there is no CPU path here.  NumPy in -> NumPy out (one upload, one
+download); device tensors in -> device tensors out (no transfer).  Results equal NumPy's bit for bit, except
+``exner`` / ``iexner`` (own ``pow``: <= 2 ulp of ``numpy.power``).
+
+The fused step kernels (K1 / K3 / K4) contain the same arithmetic and do not call these; they serve callers that use a
+helper on its own.  Host-only helpers of the reference's module that are not arithmetic on columns
+(``get_mask_indices``, ``link_dir``: shapely / file system, run once at start-up) are out of scope.
+"""
+import numpy
+import torch
+
+# Physical constants, splib/sputils.py:14-20 (plain numbers: SI-coherent units, factor 1)
+pref0 = 1e5       # Pa reference pressure
+rd = 287.04       # J/kg/K gas constant for dry air
+rv = 461.5        # J/kg/K gas constant for water vapor
+cp = 1004.        # J/kg/K specific heat at constant pressure (dry air)
+rlv = 2.53e6      # J/kg latent heat for vaporisation
+grav = 9.81       # m/s^2 gravity acceleration
+mair = 28.967     # g/mol molar mass of air
+
+
+def _engine():
+    from . import spcpl
+    eng = spcpl.get_engine()
+    return getattr(eng, "primary", eng)          # multi.MultiDeviceEngine: helpers run on its first device
+
+
+def _num(a):
+    """bare numbers of a (possibly unit-carrying) value"""
+    return a.number if hasattr(a, "number") else a
+
+
+class _Io:
+    """moves the arguments of one call to the engine's device and the result back to where they came from"""
+
+    def __init__(self):
+        self.eng = _engine()
+        self.on_device = False
+
+    def dev(self, a, dtype=None):
+        a = _num(a)
+        if isinstance(a, torch.Tensor):
+            self.on_device = self.on_device or a.device.type == "cuda"
+            return a.to(self.eng.device, dtype or self.eng.dtype)
+        a = numpy.asarray(a, dtype=numpy.float64)
+        if a.ndim:                                  # (ascontiguousarray would turn a 0-d scalar into a vector)
+            a = numpy.ascontiguousarray(a)          # negative strides ([::-1] views) included
+        return torch.from_numpy(a.copy() if not a.flags.writeable else a).to(self.eng.device, dtype or self.eng.dtype)
+
+    def back(self, t, scalar=False):
+        if self.on_device:
+            return t
+        out = t.cpu().numpy()
+        return out[()] if scalar else out
+
+
+def exner(p):
+    """Exner function (p / pref0) ** (rd / cp), splib/sputils.py:28-29"""
+    io = _Io()
+    pd = io.dev(p)
+    return io.back(io.eng.exner(pd, inverse=False), scalar=pd.dim() == 0)
+
+
+def iexner(p):
+    """inverse Exner function (p / pref0) ** (-rd / cp), splib/sputils.py:33-34"""
+    io = _Io()
+    pd = io.dev(p)
+    return io.back(io.eng.exner(pd, inverse=True), scalar=pd.dim() == 0)
+
+
+def rms(a):
+    """root mean square sqrt(mean(a ** 2)), splib/sputils.py:23-24; a 2-D argument gives the rms of every row"""
+    io = _Io()
+    ad = io.dev(a)
+    if ad.dim() == 0:
+        ad = ad.reshape(1)
+    return io.back(io.eng.rms(ad), scalar=ad.dim() == 1)
+
+
+def interp(x, xp, fp, **kwargs):
+    """numpy.interp(x, xp, fp) (splib/sputils.py:82-86) for one column (1-D arguments) or for every row of 2-D arguments
+    (x and xp may stay 1-D: shared by all rows).  numpy.interp's left / right / period are not supported."""
+    if kwargs:
+        raise NotImplementedError("sputils.interp on the GPU: numpy.interp's %s not supported" % sorted(kwargs))
+    io = _Io()
+    xd, xpd, fpd = io.dev(x), io.dev(xp), io.dev(fp)
+    scalar = xd.dim() == 0
+    if scalar:
+        xd = xd.reshape(1)
+    r = io.eng.interp(xd, xpd, fpd)
+    return io.back(r[..., 0] if scalar else r, scalar=scalar and r.dim() == 1)
+
+
+def searchsorted(a, v, **kwargs):
+    """numpy.searchsorted(a, v, side=...) (splib/sputils.py:88-91) for one column or per row; int64 indices"""
+    side = kwargs.pop("side", "left")
+    if kwargs:
+        raise NotImplementedError("sputils.searchsorted on the GPU: numpy.searchsorted's %s not supported" % sorted(kwargs))
+    io = _Io()
+    ad, vd = io.dev(a), io.dev(v)
+    scalar = vd.dim() == 0
+    if scalar:
+        vd = vd.reshape(1)
+    r = io.eng.searchsorted(ad, vd, side=side)
+    return io.back(r[..., 0] if scalar else r, scalar=scalar and r.dim() == 1)
+
+
+def integral(a, b, z, q, w=None):
+    """integral from a to b of the piece-wise constant q(z) (value q[i] on [z[i], z[i+1]]), optionally weighted by w:
+    splib/sputils.py:94-161.  Returns None when an end point lies outside z, as the reference does (scalar call); with
+    arrays a, b of n_rows end points (and 2-D z / q / w or shared 1-D z) the rows outside give NaN."""
+    io = _Io()
+    ad, bd = io.dev(a), io.dev(b)
+    scalar = ad.dim() == 0 and bd.dim() == 0
+    Zh = torch.stack([bd.reshape(-1), ad.reshape(-1)], dim=1)            # layer k = [Zh[k+1], Zh[k]] = [a, b]
+    zd, qd = io.dev(z), io.dev(q)
+    wd = io.dev(w) if w is not None else None
+    if scalar:
+        if zd.shape[-1] != qd.shape[-1] + 1:
+            print("len(z) should be len(q) + 1. len(z)=%d, len(q) = %d", (zd.shape[-1], qd.shape[-1]))      # sputils.py:111-112
+        r = io.eng.interp_c(Zh[0], zd, qd, wd, mode="integral")
+        val = float(r[0])
+        if val != val and not bool(torch.isnan(ad) | torch.isnan(bd)):
+            lo, hi = float(zd[0]), float(zd[-1])
+            if float(ad) < lo or float(ad) > hi or float(bd) < lo or float(bd) > hi:
+                print("integral: Interval end point outside range.")                                       # sputils.py:114
+                return None
+        return r[0] if io.on_device else val
+    if qd.dim() == 1:
+        qd = qd.unsqueeze(0).expand(Zh.shape[0], -1)
+        wd = wd.unsqueeze(0).expand(Zh.shape[0], -1) if wd is not None else None
+    r = io.eng.interp_c(Zh, zd, qd, wd, mode="integral")
+    return io.back(r[:, 0])
+
+
+def interp_c(Zh, zh, q, rho):
+    """conservative interpolation from fine to coarse levels (splib/sputils.py:173-189): Q[i] = rho-weighted mean of q over
+    [Zh[i+1], Zh[i]] where Zh[i] < zh[-1], else 0.  One column (1-D) or [n_cols x ...] batches (zh may stay 1-D)."""
+    io = _Io()
+    return io.back(io.eng.interp_c(io.dev(Zh), io.dev(zh), io.dev(q), io.dev(rho), mode="interp_c"))
+
+
+def interp_rho(Zh, zh, rho):
+    """a density on the coarser grid (splib/sputils.py:191-197): integral(Zh[i+1], Zh[i], zh, rho) / (Zh[i] - Zh[i+1])"""
+    io = _Io()
+    return io.back(io.eng.interp_c(io.dev(Zh), io.dev(zh), io.dev(rho), None, mode="interp_rho"))
+
+
+def find_closest_points(points, target):
+    """indices of ``points`` sorted by great-circle distance to ``target`` (splib/sputils.py:40-42 with splib/haversine.py:
+    first coordinate = longitude, second = latitude, 6371 km sphere).  Start-up geometry on a handful of grid points,
+    not column arithmetic: plain host code, as in the reference."""
+    lng1, lat1 = numpy.radians(numpy.asarray(points, dtype=numpy.float64)).T
+    lng2, lat2 = numpy.radians(numpy.asarray(target, dtype=numpy.float64))
+    d = numpy.sin((lat2 - lat1) * 0.5) ** 2 + numpy.cos(lat1) * numpy.cos(lat2) * numpy.sin((lng2 - lng1) * 0.5) ** 2
+    return numpy.argsort(2 * 6371 * numpy.arcsin(numpy.sqrt(d)))

@@ -34,7 +34,7 @@ def test_header_symbols_all_exported_and_bound(lib):
 
 
 def test_abi_version_and_error_text(lib):
-    assert lib.spc_abi_version() == _abi.ABI_VERSION == 3
+    assert lib.spc_abi_version() == _abi.ABI_VERSION == 4
     assert isinstance(lib.spc_last_error(), bytes)
 
 
@@ -44,7 +44,10 @@ def test_struct_layout_matches_c_compiler(tmp_path):
               ("spc_forward_args", _abi.ForwardArgs, ["U", "zf", "rain_last", "factor", "dt", "f_u", "idx", "Z0M", "wqt"]),
               ("spc_backward_args", _abi.BackwardArgs, ["T", "A_prof", "rhobf_d", "conservative", "factor", "dt", "f_T", "start_index"]),
               ("spc_diagnostics_args", _abi.DiagnosticsArgs, ["T", "zf", "Tv", "ql_water"]),
-              ("spc_vnudge_args", _abi.VnudgeArgs, ["n_cols", "itot", "ktot", "constantT", "qt", "R", "presf", "beta", "status", "work", "work_bytes"])]
+              ("spc_vnudge_args", _abi.VnudgeArgs, ["n_cols", "itot", "ktot", "constantT", "qt", "R", "presf", "beta", "status", "work", "work_bytes"]),
+              ("spc_interp_args", _abi.InterpArgs, ["n_rows", "n_x", "n_xp", "pitch_x", "pitch_out", "x", "fp", "out"]),
+              ("spc_searchsorted_args", _abi.SearchsortedArgs, ["n_rows", "n_a", "n_v", "pitch_a", "pitch_out", "a", "out", "side_right"]),
+              ("spc_interp_c_args", _abi.InterpCArgs, ["n_rows", "nG", "nL", "pitch_Zh", "pitch_zh", "pitch_q", "pitch_out", "Zh", "rho", "out", "mode"])]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "spc.h"', 'int main(void){']
     for cname, _, fields in probes:
         lines.append('printf("%%zu\\n", sizeof(%s));' % cname)
@@ -137,3 +140,43 @@ def test_engine_refuses_to_run_without_gpu(lib):
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         Engine()
+
+
+def test_sputils_operators_validate_on_the_host(lib):
+    """K7 entry points (spc_exner / interp / searchsorted / interp_c / rms): argument checks before any launch"""
+    E = _abi.SPC_ERR_INVALID_ARGUMENT
+    assert lib.spc_exner_f64(0, None, None, 0, None) == 0                       # empty: no-op
+    assert lib.spc_exner_f64(8, None, None, 0, None) == E and b"NULL" in lib.spc_last_error()
+    assert lib.spc_exner_f32(-1, None, None, 1, None) == E
+    a = _abi.InterpArgs(4, 160, 0, 160, 91, 91, 160, 1, 1, 1, 1)                # empty sample array: numpy raises ValueError
+    assert lib.spc_interp_f64(ctypes.byref(a), None) == E and b"empty" in lib.spc_last_error()
+    a = _abi.InterpArgs(4, 160, 91, 100, 91, 91, 160, 1, 1, 1, 1)               # pitch_x < n_x
+    assert lib.spc_interp_f64(ctypes.byref(a), None) == E and b"pitch" in lib.spc_last_error()
+    a = _abi.InterpArgs(4, 160, 91, 0, 0, 91, 160, None, None, None, None)
+    assert lib.spc_interp_f32(ctypes.byref(a), None) == E and b"NULL" in lib.spc_last_error()
+    assert lib.spc_interp_f64(ctypes.byref(_abi.InterpArgs(0, 160, 91, 0, 0, 91, 160)), None) == 0
+    s = _abi.SearchsortedArgs(4, 160, 92, 0, 92, 10, 1, 1, 1, 1, 0)             # pitch_out < n_v
+    assert lib.spc_searchsorted_f64(ctypes.byref(s), None) == E
+    c = _abi.InterpCArgs(4, 91, 160, 92, 0, 160, 91, 1, 1, 1, None, 1, 0, 0)    # interp_c without weights
+    assert lib.spc_interp_c_f64(ctypes.byref(c), None) == E and b"rho" in lib.spc_last_error()
+    c = _abi.InterpCArgs(4, 91, 1, 92, 0, 160, 91, 1, 1, 1, 1, 1, 0, 0)         # one grid point bounds no cell
+    assert lib.spc_interp_c_f64(ctypes.byref(c), None) == E
+    c = _abi.InterpCArgs(4, 91, 160, 92, 0, 160, 91, 1, 1, 1, 1, 1, 7, 0)
+    assert lib.spc_interp_c_f32(ctypes.byref(c), None) == E and b"mode" in lib.spc_last_error()
+    assert lib.spc_rms_f64(3, 160, 100, None, None, None) == E
+    assert lib.spc_rms_f64(0, 160, 160, None, None, None) == 0
+
+
+def test_sputils_module_fails_loudly_without_a_gpu():
+    """the GPU twin of splib/sputils.py has no CPU path: without a HIP device the first call raises"""
+    import numpy
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from sp_coupler_amd import spcpl, sputils
+    spcpl.set_engine(None)
+    assert sputils.rd == 287.04 and sputils.cp == 1004. and sputils.pref0 == 1e5          # sputils.py:14-20
+    for call in (lambda: sputils.exner(1e5), lambda: sputils.interp(numpy.zeros(2), numpy.arange(3.), numpy.arange(3.)),
+                 lambda: sputils.rms(numpy.ones(3))):
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            call()

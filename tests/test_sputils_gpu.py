@@ -1,0 +1,211 @@
+"""K7: the helpers of splib/sputils.py as standalone GPU operators (sp_coupler_amd/sputils.py over spc_exner_* /
+spc_interp_* / spc_searchsorted_* / spc_interp_c_* / spc_rms_* of the C ABI).
+
+* the reference's own test file for these helpers (splib/test/sputils_test.py:10-47) restated against the GPU module:
+  same numbers, same assertions, same tolerance (1e-10) -- these pin exner / iexner / rms;
+* bit parity with NumPy (numpy.interp / numpy.searchsorted are what the reference calls) and with the oracle's
+  restatement of integral / interp_c / interp_rho (parity unpinned by the reference: it holds no fixture for them)."""
+import json
+import os
+
+import numpy
+import pytest
+import torch
+
+from oracle import spcpl_oracle as orc
+from sp_coupler_amd import synthetic
+from tests.gpu_util import EPS, assert_bits
+
+pytestmark = pytest.mark.gpu
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_known_answers.json")))
+
+
+@pytest.fixture(scope="module")
+def sputils():
+    from sp_coupler_amd import spcpl, sputils as su
+    from sp_coupler_amd.engine import Engine
+    spcpl.set_engine(Engine("cuda:0"))
+    yield su
+    spcpl.set_engine(None)
+
+
+class TestReferenceSputilsTest:
+    """splib/test/sputils_test.py, every test of the class, through the GPU module"""
+    tolerance = 1.e-10
+
+    def test_rms(self, sputils):
+        a, b, c = 3.204, -1.2092, 9.6231
+        assert abs(sputils.rms(numpy.array([a, b, c])) - numpy.sqrt((a * a + b * b + c * c) / 3)) < self.tolerance
+
+    def test_rms_repeat(self, sputils):
+        a, n = 3.204, 23
+        assert abs(sputils.rms(numpy.array([a for i in range(n)])) - a) < self.tolerance
+
+    def test_exner(self, sputils):
+        a = 2.03947
+        p = a * sputils.pref0
+        assert abs(numpy.log(sputils.exner(p)) - numpy.log(a) * sputils.rd / sputils.cp) < self.tolerance
+
+    def test_exner_unity(self, sputils):
+        assert abs(sputils.exner(sputils.pref0) - 1) < self.tolerance
+        assert numpy.ndim(sputils.exner(sputils.pref0)) == 0          # a scalar in, a scalar out
+
+    def test_iexner(self, sputils):
+        p = 12.03947 * sputils.pref0
+        assert abs(sputils.exner(p) * sputils.iexner(p) - 1) < self.tolerance
+
+    def test_get_closest_points(self, sputils):
+        points = [(52.314970, 4.824198), (52.379932, 4.897997), (52.387264, 5.082968), (52.278097, 5.021635)]
+        assert sputils.find_closest_points(points, (52.356591, 4.954541))[0] == 1
+
+
+def test_known_answers_of_the_reference(sputils):
+    g = GOLD
+    assert abs(sputils.exner(g["exner"]["a"] * g["exner"]["pref0"]) - g["exner"]["expected"]) < g["tolerance"]
+    assert abs(sputils.exner(g["exner_unity"]["p"]) - 1.0) < g["tolerance"]
+    assert abs(sputils.rms(numpy.array(g["rms"]["numbers"])) - g["rms"]["expected"]) < g["tolerance"]
+    cf = g["cloud_fraction"]                   # spcpl.py:26: searchsorted(zh, Zh, side="right")[:-1][::-1] == [0, 0, 1, 5, 20]
+    zh, Zh = numpy.array(cf["zh"], dtype=float), numpy.array(cf["gcm_Zh"], dtype=float)
+    idx = sputils.searchsorted(zh, Zh, side="right")
+    assert idx.dtype == numpy.int64 and idx[:-1][::-1].tolist() == cf["indices"]
+
+
+def test_exner_accuracy_and_shapes(sputils):
+    rng = numpy.random.default_rng(11)
+    p = rng.uniform(1.0, 1.1e5, size=(37, 91))
+    for fn, ref in ((sputils.exner, orc.exner), (sputils.iexner, orc.iexner)):
+        got, want = fn(p), ref(p)
+        assert got.shape == want.shape and got.dtype == numpy.float64
+        assert (numpy.abs(got - want) <= 2 * EPS * numpy.abs(want)).all()          # own pow: <= 2 ulp of numpy.power
+    dev = torch.from_numpy(p).cuda()
+    r = sputils.iexner(dev)
+    assert isinstance(r, torch.Tensor) and r.is_cuda and numpy.array_equal(r.cpu().numpy(), sputils.iexner(p))
+
+
+def _interp_rows(x, xp, fp):
+    n = max(a.shape[0] if a.ndim == 2 else 1 for a in (x, xp, fp))
+    row = lambda a, r: a[r] if a.ndim == 2 else a      # noqa: E731
+    with numpy.errstate(all="ignore"):
+        return numpy.stack([numpy.interp(row(x, r), row(xp, r), row(fp, r)) for r in range(n)])
+
+
+def test_interp_is_numpy_interp_bit_for_bit(sputils):
+    rng = numpy.random.default_rng(5)
+    n, n_xp, n_x = 300, 91, 160
+    xp = numpy.sort(rng.uniform(0, 3e4, size=(n, n_xp)), axis=1)
+    fp = rng.normal(size=(n, n_xp)) * 10
+    x = rng.uniform(-500, 3.1e4, size=(n, n_x))
+    x[:, 3] = xp[:, 7]                       # exact hits
+    x[:, 4] = xp[:, 0]; x[:, 5] = xp[:, -1]
+    x[5, 9] = numpy.nan; x[6, 10] = numpy.inf; x[7, 11] = -numpy.inf
+    fp[9, 20] = numpy.nan; fp[10, 30] = numpy.inf
+    xp[11, 40] = xp[11, 41]                  # a repeated sample point: zero dx
+    assert_bits("interp per-row", sputils.interp(x, xp, fp), _interp_rows(x, xp, fp))
+    assert_bits("interp shared xp", sputils.interp(x, xp[0], fp), _interp_rows(x, xp[0], fp))
+    assert_bits("interp shared x", sputils.interp(x[0], xp, fp), _interp_rows(x[0], xp, fp))
+    # one column, the way the reference calls it (spcpl.py:224: reversed views of the GCM arrays)
+    Zf, thl = xp[3][::-1], fp[3][::-1]
+    assert_bits("interp 1-D reversed views", sputils.interp(x[3], Zf[::-1], thl[::-1]), numpy.interp(x[3], xp[3], fp[3]))
+    assert sputils.interp(1234.5, xp[3], fp[3]) == numpy.interp(1234.5, xp[3], fp[3])        # scalar x
+    # a single sample point, and sample arrays too long for the LDS (read from global memory)
+    assert_bits("interp n_xp=1", sputils.interp(x[:4], xp[:4, :1], fp[:4, :1]), _interp_rows(x[:4], xp[:4, :1], fp[:4, :1]))
+    big = numpy.sort(rng.uniform(0, 1, size=(3, 9000)), axis=1)
+    bf, bx = rng.normal(size=(3, 9000)), rng.uniform(-0.1, 1.1, size=(3, 50))
+    assert_bits("interp n_xp=9000", sputils.interp(bx, big, bf), _interp_rows(bx, big, bf))
+    # device tensors in, device tensor out
+    r = sputils.interp(torch.from_numpy(x).cuda(), torch.from_numpy(xp).cuda(), torch.from_numpy(fp).cuda())
+    assert r.is_cuda
+    assert_bits("interp device", r.cpu().numpy(), _interp_rows(x, xp, fp))
+
+
+def test_interp_errors_like_numpy(sputils):
+    with pytest.raises(ValueError):
+        sputils.interp(numpy.zeros(3), numpy.zeros(4), numpy.zeros(5))       # fp and xp are not of the same length
+    with pytest.raises(ValueError):
+        sputils.interp(numpy.zeros(3), numpy.zeros(0), numpy.zeros(0))       # array of sample points is empty
+    with pytest.raises(NotImplementedError):
+        sputils.interp(numpy.zeros(3), numpy.arange(4.), numpy.arange(4.), left=0.0)
+
+
+def test_searchsorted_is_numpy_searchsorted(sputils):
+    rng = numpy.random.default_rng(6)
+    n, n_a, n_v = 200, 160, 92
+    a = numpy.sort(rng.uniform(0, 4000, size=(n, n_a)), axis=1)
+    v = rng.uniform(-100, 4100, size=(n, n_v))
+    v[:, 2] = a[:, 17]; v[:, 3] = a[:, 0]; v[:, 4] = a[:, -1]; v[3, 5] = numpy.nan
+    a[4, 50] = a[4, 51]
+    for side in ("left", "right"):
+        want = numpy.stack([numpy.searchsorted(a[r], v[r], side=side) for r in range(n)])
+        got = sputils.searchsorted(a, v, side=side)
+        assert got.dtype == numpy.int64 and numpy.array_equal(got, want), side
+        assert numpy.array_equal(sputils.searchsorted(a[0], v, side=side),
+                                 numpy.stack([numpy.searchsorted(a[0], v[r], side=side) for r in range(n)]))
+        assert numpy.array_equal(sputils.searchsorted(a[7], v[7], side=side), numpy.searchsorted(a[7], v[7], side=side))
+    assert sputils.searchsorted(a[7], 1234.5) == numpy.searchsorted(a[7], 1234.5)
+    assert numpy.array_equal(sputils.searchsorted(numpy.zeros(0), v[0]), numpy.searchsorted(numpy.zeros(0), v[0]))
+
+
+def _coarse_inputs(n, nG, nL, seed, per_column_grid=False):
+    gcm, zf, zh, prof = synthetic.make_batch(n, nG, nL, seed=seed, couple_surface=False, per_column_grid=per_column_grid)
+    Zh = numpy.stack([orc.convert_profiles({k: v[c] for k, v in gcm.items()}, zf[c] if zf.ndim == 2 else zf)["Zh"] for c in range(n)])
+    return Zh, zh, prof["QT"], prof["Rhobf"]
+
+
+@pytest.mark.parametrize("nG,nL,per_col", [(91, 160, False), (19, 160, True), (31, 2000, False)])
+def test_interp_c_and_interp_rho_match_the_oracle(sputils, nG, nL, per_col):
+    n = 40
+    Zh, zh, q, rho = _coarse_inputs(n, nG, nL, seed=77, per_column_grid=per_col)
+    Zh[5, nG // 2] = -3.0                                   # an end point below zh[0]: integral() returns None -> NaN
+    z = lambda c: zh[c] if zh.ndim == 2 else zh             # noqa: E731
+    with numpy.errstate(all="ignore"):
+        want_c = numpy.stack([orc.interp_c(Zh[c], z(c), q[c], rho[c]) for c in range(n)])
+    got_c = sputils.interp_c(Zh, zh, q, rho)
+    assert_bits("interp_c", got_c, want_c)
+    assert numpy.isnan(got_c[5]).any() and (got_c != 0).any()
+    assert_bits("interp_c one column", sputils.interp_c(Zh[2], z(2), q[2], rho[2]), want_c[2])
+    Zr = numpy.delete(Zh, 5, axis=0)                         # interp_rho divides None by a number in the reference
+    zr = numpy.delete(zh, 5, axis=0) if zh.ndim == 2 else zh
+    rr = numpy.delete(rho, 5, axis=0)
+    want_r = numpy.stack([orc.interp_rho(Zr[c], zr[c] if zr.ndim == 2 else zr, rr[c]) for c in range(n - 1)])
+    assert_bits("interp_rho", sputils.interp_rho(Zr, zr, rr), want_r)
+
+
+def test_integral_like_the_reference(sputils):
+    rng = numpy.random.default_rng(8)
+    z = numpy.cumsum(rng.uniform(5, 40, size=300))
+    q, w = rng.normal(size=299), rng.uniform(0.5, 1.3, size=299)
+    for a, b in ((z[3] + 1.0, z[200] - 2.0), (z[250], z[10] + 0.5), (z[0], z[-1]), (z[7], z[7]), (z[4] + 1, z[4] + 2)):
+        for ww in (None, w):
+            got, want = sputils.integral(a, b, z, q, ww), orc.integral(a, b, z, q, ww)
+            assert got == want or (got != got and want != want), (a, b, ww is None, got, want)
+    assert sputils.integral(z[0] - 1.0, z[5], z, q) is None                    # sputils.py:113-115
+    assert sputils.integral(z[3], z[-1] + 1.0, z, q, w) is None
+    # many intervals at once (beyond the reference): rows outside the grid give NaN
+    a = rng.uniform(z[0], z[-1], size=64); b = rng.uniform(z[0], z[-1], size=64); a[9] = z[0] - 5
+    got = sputils.integral(a, b, z, q, w)
+    want = numpy.array([numpy.nan if i == 9 else orc.integral(a[i], b[i], z, q, w) for i in range(64)])
+    assert_bits("integral batch", got, want)
+
+
+def test_rms_rows_in_numpy_order(sputils):
+    rng = numpy.random.default_rng(9)
+    a = rng.normal(size=(33, 160)) * rng.uniform(1e-3, 1e3, size=(33, 1))
+    assert_bits("rms rows", sputils.rms(a), numpy.array([orc.rms(a[r]) for r in range(33)]))
+    long = rng.normal(size=20011)                                              # > 8192: numpy's chunked pairwise order
+    assert sputils.rms(long) == orc.rms(long)
+
+
+def test_float32_engine_runs_the_helpers():
+    from sp_coupler_amd.engine import Engine
+    eng = Engine("cuda:0", dtype=torch.float32)
+    rng = numpy.random.default_rng(10)
+    xp = numpy.sort(rng.uniform(0, 3e4, size=(50, 91)), axis=1).astype(numpy.float32)
+    fp = rng.normal(size=(50, 91)).astype(numpy.float32)
+    x = rng.uniform(0, 3e4, size=(50, 160)).astype(numpy.float32)
+    got = eng.interp(torch.from_numpy(x).cuda(), torch.from_numpy(xp).cuda(), torch.from_numpy(fp).cuda()).cpu().numpy()
+    want = _interp_rows(x.astype(float), xp.astype(float), fp.astype(float))
+    assert numpy.abs(got - want).max() <= 1e-4 * numpy.abs(want).max()
+    idx = eng.searchsorted(torch.from_numpy(xp).cuda(), torch.from_numpy(x).cuda(), side="right").cpu().numpy()
+    assert numpy.array_equal(idx, numpy.stack([numpy.searchsorted(xp[r], x[r], side="right") for r in range(50)]))
+    p = torch.from_numpy(rng.uniform(1e4, 1.05e5, size=1000).astype(numpy.float32)).cuda()
+    assert numpy.allclose(eng.exner(p).cpu().numpy(), orc.exner(p.cpu().numpy().astype(float)), rtol=2e-6)

@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--levels", default="91,160")
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--vn-cols", default="2,64")
+    ap.add_argument("--sputils", action="store_true", help="also time the K7 operators (sputils helpers on their own) at every size")
     ap.add_argument("--k4-cbs", default="0", help="cols_per_block settings for K4 (0 = the library's choice)")
     ap.add_argument("--vn-shapes", default="64x64x160", help="LES field extents itot x jtot x ktot, comma separated")
     ap.add_argument("--vn-modes", default="default", help="default (LDS / streamed planes), sweep (SPC_VN_LDS=0: the sweeping kernel)")
@@ -66,6 +67,23 @@ def main():
         print("n=%d %d<->%d | K3 %.1f us %.0f GB/s | K4 (conservative) %.1f us %.0f GB/s (%.2fx K3) | K5 gcm-level %.1f us %.0f GB/s | "
               "K5 +les-level %.1f us %.0f GB/s" % (n, nG, nL, t3, b3 / t3 / 1e3, t4, b4 / t4 / 1e3, t4 / t3, t5a, b5a / t5a / 1e3,
                                                  t5b, b5b / t5b / 1e3), flush=True)
+    for n in (int(x) for x in a.sizes.split(",") if x and a.sputils):
+        # K7: the helpers of splib/sputils.py as standalone operators, on the arrays K1 / K3 / K4 work on
+        gcm, zf, zh, prof = synthetic.make_batch_tiled(n, nG, nL, seed=78, couple_surface=False)
+        dev = lambda x: torch.from_numpy(numpy.ascontiguousarray(x)).cuda()      # noqa: E731
+        Zf = dev(((gcm["Zgfull"] - gcm["Zghalf"][:, -1:]) / 9.81)[:, ::-1])       # ascending, as spcpl.py:224 passes it
+        Zh = dev((gcm["Zghalf"] - gcm["Zghalf"][:, -1:]) / 9.81)
+        T_, Pf = dev(gcm["T"][:, ::-1]), dev(gcm["Pfull"])
+        zf_d, zh_d, qt, rho = dev(zf), dev(zh), dev(prof["QT"]), dev(prof["Rhobf"])
+        rows = [("interp GCM->LES (x shared [nL], xp/fp per row [nG])", lambda: eng.interp(zf_d, Zf, T_), n * (2 * nG + nL) * 8),
+                ("interp LES->GCM (x per row [nG], xp shared [nL])", lambda: eng.interp(Zf, zf_d, qt), n * (nG + nL + nG) * 8),
+                ("searchsorted(zh, Zh, right)", lambda: eng.searchsorted(zh_d, Zh, side="right"), n * (2 * (nG + 1)) * 8),
+                ("iexner(Pfull)", lambda: eng.exner(Pf, inverse=True), n * 2 * nG * 8),
+                ("interp_c(Zh, zh, qt, rhobf)", lambda: eng.interp_c(Zh, zh_d, qt, rho), n * (nG + 1 + 2 * nL + nG) * 8),
+                ("rms rows [n x nL]", lambda: eng.rms(qt), n * (nL + 1) * 8)]
+        for name, fn, nbytes in rows:
+            t = timed(fn, a.iters)
+            print("n=%d K7 %-52s %8.1f us %6.0f GB/s (algorithmic bytes; the output allocation is inside the call)" % (n, name, t, nbytes / t / 1e3), flush=True)
     from tests.test_vnudge import make_les_fields
     for shape in (x for x in a.vn_shapes.split(",") if x):
         it, jt, kt = (int(v) for v in shape.split("x"))

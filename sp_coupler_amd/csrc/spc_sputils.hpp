@@ -104,9 +104,20 @@ template <typename T> __global__ __launch_bounds__(SU_THREADS) void k_searchsort
     }
 }
 
+enum { SU_INTERP_C = 0, SU_INTERP_RHO = 1, SU_INTEGRAL = 2 };
+
+struct SuCoarseP {
+    int64_t n_rows, pitch_Zh, pitch_zh, pitch_q, pitch_out;
+    int nG, nL, mode, stage, rb;
+    const void *Zh, *zh, *q, *rho;
+    void *out;
+};
+
 // integral() of splib/sputils.py:94-161 over [a, b] of the piecewise-constant q on the cells of z (n points), optional
-// weights w.  *none: an end point lies outside z (the reference prints a message and returns None).
-template <typename T> __device__ T su_integral(T a, T b, const T *z, int n, const T *qv, const T *w, bool *none)
+// weights w.  *none: an end point lies outside z (the reference prints a message and returns None).  The (up to two)
+// sums of a call -- sum w q dz and sum w dz -- run through ONE instance of the summation code (`pass`), and numpy's
+// pairwise recursion is unrolled to the depth PD the host derived from n (as in K4; PD = -1: explicit stack).
+template <typename T, int PD> __device__ __forceinline__ T su_integral(T a, T b, const T *z, int n, const T *qv, const T *w, bool weighted, bool *none)
 {
     *none = false;
     if (a < z[0] || a > z[n - 1] || b < z[0] || b > z[n - 1]) { *none = true; return T(0); }     // sputils.py:113-115
@@ -117,57 +128,62 @@ template <typename T> __device__ T su_integral(T a, T b, const T *z, int n, cons
     if (ib < ia) ib = ia;
     const int cnt = ib - ia + 1;
     const T da = a - z[ia], db = z[ib + 1] - b;
-    if (!w) {
-        auto term = [&](int i) { return qv[ia + i] * (z[ia + i + 1] - z[ia + i]); };               // sputils.py:146
-        const T S = cnt <= 128 ? T(0) + vn_leaf(term, 0, cnt) : vn_npsum(term, cnt);
-        return ((S - qv[ia] * da) - qv[ib] * db) * sign;                                           // sputils.py:149-152
+    T num = T(0), den = T(1);
+    const int npass = weighted ? 2 : 1;
+#pragma unroll 1
+    for (int pass = 0; pass < npass; ++pass) {
+        // pass 0: q dz (sputils.py:146) or (w q) dz (:154); pass 1: w dz (:159)
+        auto val = [&](int i) { return pass ? w[i] : (weighted ? w[i] * qv[i] : qv[i]); };
+        auto term = [&](int i) { return val(ia + i) * (z[ia + i + 1] - z[ia + i]); };
+        T S;
+        if constexpr (PD >= 0) S = T(0) + vn_pw<PD>(term, 0, cnt);
+        else S = cnt <= 128 ? T(0) + vn_leaf(term, 0, cnt) : vn_npsum(term, cnt);
+        const T v = (S - val(ia) * da) - val(ib) * db;                                             // sputils.py:149-152, 156-162
+        if (pass) den = v; else num = v;
     }
-    auto term = [&](int i) { return (w[ia + i] * qv[ia + i]) * (z[ia + i + 1] - z[ia + i]); };      // sputils.py:154
-    auto termw = [&](int i) { return w[ia + i] * (z[ia + i + 1] - z[ia + i]); };                   // sputils.py:159
-    const T S = cnt <= 128 ? T(0) + vn_leaf(term, 0, cnt) : vn_npsum(term, cnt);
-    const T Sw = cnt <= 128 ? T(0) + vn_leaf(termw, 0, cnt) : vn_npsum(termw, cnt);
-    const T num = (S - (w[ia] * qv[ia]) * da) - (w[ib] * qv[ib]) * db;                             // sputils.py:156-157
-    const T den = (Sw - w[ia] * da) - w[ib] * db;                                                  // sputils.py:161-162
-    return num / den * sign;
+    return weighted ? num / den * sign : num * sign;
 }
 
-enum { SU_INTERP_C = 0, SU_INTERP_RHO = 1, SU_INTEGRAL = 2 };
-
-struct SuCoarseP {
-    int64_t n_rows, pitch_Zh, pitch_zh, pitch_q, pitch_out;
-    int nG, nL, mode, stage;
-    const void *Zh, *zh, *q, *rho;
-    void *out;
-};
-
-// one workgroup per row; thread k: the layer [Zh[k+1], Zh[k]]
-template <typename T> __global__ __launch_bounds__(SU_THREADS) void k_interp_c(const SuCoarseP p)
+// RB rows per workgroup; thread = (row, layer k): the layer [Zh[k+1], Zh[k]].  STAGE: the rows' zh, q, rho go through LDS
+// (a compile-time switch: mixing LDS and global addresses in one pointer makes every access a 64-bit flat one).
+template <typename T, int PD, bool STAGE> __global__ __launch_bounds__(SU_THREADS) void k_interp_c(const SuCoarseP p)
 {
     T *const lds = reinterpret_cast<T *>(spc_smem);
-    const int64_t row = blockIdx.x;
-    const int nL = p.nL, tid = threadIdx.x;
-    const T *z = (const T *)p.zh + row * p.pitch_zh, *qv = (const T *)p.q + row * p.pitch_q;
-    const T *w = p.rho ? (const T *)p.rho + row * p.pitch_q : nullptr;
-    const T *const Zh = (const T *)p.Zh + row * p.pitch_Zh;
-    if (p.stage) {                                  // z[nL] | q[nL] | rho[nL]
-        for (int e = tid; e < nL; e += SU_THREADS) {
-            lds[e] = z[e];
-            lds[nL + e] = e < nL - 1 ? qv[e] : T(0);          // nL points bound nL - 1 cells: the last element is never used
-            if (w) lds[2 * nL + e] = e < nL - 1 ? w[e] : T(0);
+    const int64_t row0 = (int64_t)blockIdx.x * p.rb;
+    const int nrow = (int)((p.n_rows - row0) < p.rb ? (p.n_rows - row0) : p.rb);
+    const int nL = p.nL, nG = p.nG, tid = threadIdx.x;
+    const T *const zg = (const T *)p.zh, *const qg = (const T *)p.q, *const wg = (const T *)p.rho;
+    // LDS: q[rb][nL] | rho[rb][nL] | z[rb][nL] (or z[nL] when shared)
+    T *const lq = lds, *const lw = lds + (size_t)p.rb * nL, *const lz = lw + (size_t)p.rb * nL;
+    if constexpr (STAGE) {
+        for (int e = tid; e < nrow * nL; e += SU_THREADS) {
+            const int r = e / nL, l = e - r * nL;
+            const int64_t o = (row0 + r) * p.pitch_q + l;
+            lq[e] = l < nL - 1 ? qg[o] : T(0);                // nL points bound nL - 1 cells: the last element is never used
+            if (wg) lw[e] = l < nL - 1 ? wg[o] : T(0);
+            if (p.pitch_zh) lz[e] = zg[(row0 + r) * p.pitch_zh + l];
         }
+        if (!p.pitch_zh)
+            for (int e = tid; e < nL; e += SU_THREADS) lz[e] = zg[e];
         __syncthreads();
-        z = lds; qv = lds + nL; if (w) w = lds + 2 * nL;
     }
-    for (int k = tid; k < p.nG; k += SU_THREADS) {
+    for (int e = tid; e < nrow * nG; e += SU_THREADS) {
+        const int r = e / nG, k = e - r * nG;
+        const int64_t row = row0 + r;
+        const T *const z = STAGE ? lz + (p.pitch_zh ? (size_t)r * nL : 0) : zg + row * p.pitch_zh;
+        const T *const qv = STAGE ? lq + (size_t)r * nL : qg + row * p.pitch_q;
+        const T *const wr = STAGE ? lw + (size_t)r * nL : wg + row * p.pitch_q;
+        const bool weighted = wg != nullptr;
+        const T *const Zh = (const T *)p.Zh + row * p.pitch_Zh;
         const T top = Zh[k], bot = Zh[k + 1];
-        T r = T(0);                                                                    // Q = zeros / RHO = zeros
+        T res = T(0);                                                                  // Q = zeros / RHO = zeros
         if (p.mode == SU_INTEGRAL || top < z[nL - 1]) {                                // sputils.py:187 / 195
             bool none;
-            r = su_integral(bot, top, z, nL, qv, p.mode == SU_INTERP_RHO ? (const T *)nullptr : w, &none);
-            if (none) r = T(0) / T(0);                                                 // Q[i] = None stores NaN (numpy 2.x)
-            else if (p.mode == SU_INTERP_RHO) r = r / (top - bot);                      // sputils.py:196
+            res = su_integral<T, PD>(bot, top, z, nL, qv, wr, weighted, &none);
+            if (none) res = T(0) / T(0);                                               // Q[i] = None stores NaN (numpy 2.x)
+            else if (p.mode == SU_INTERP_RHO) res = res / (top - bot);                  // sputils.py:196
         }
-        ((T *)p.out)[row * p.pitch_out + k] = r;
+        ((T *)p.out)[row * p.pitch_out + k] = res;
     }
 }
 

@@ -84,9 +84,16 @@ template <typename T> int interp_c_impl(const spc_interp_c_args *a, void *stream
     q.n_rows = a->n_rows; q.pitch_Zh = a->pitch_Zh; q.pitch_zh = a->pitch_zh; q.pitch_q = a->pitch_q; q.pitch_out = a->pitch_out;
     q.nG = a->nG; q.nL = a->nL; q.mode = a->mode;
     q.Zh = a->Zh; q.zh = a->zh; q.q = a->q; q.rho = a->mode == SU_INTERP_RHO ? nullptr : a->rho; q.out = a->out;
-    q.stage = (size_t)3 * a->nL * sizeof(T) <= SU_MAX_LDS;
-    const size_t smem = q.stage ? (size_t)3 * a->nL * sizeof(T) : 0;
-    hipLaunchKernelGGL(k_interp_c<T>, dim3((unsigned)a->n_rows), dim3(SU_THREADS), smem, (hipStream_t)stream, q);
+    q.rb = su_rows_per_block(a->nG, (size_t)a->nL * (a->pitch_zh ? 3 : 2), a->pitch_zh ? 0 : a->nL, sizeof(T), &q.stage);
+    const size_t smem = q.stage ? ((size_t)a->nL * (a->pitch_zh ? 3 : 2) * q.rb + (a->pitch_zh ? 0 : a->nL)) * sizeof(T) : 0;
+    // numpy's pairwise recursion unrolled to the depth a layer of <= nL - 1 cells needs (cons_depth, as K4); the float twin
+    // and grids of more than 1024 points keep the explicit stack
+    const int pd = sizeof(T) == 8 ? cons_depth(a->nL) : -1;
+    void (*kern)(const SuCoarseP) = q.stage ? k_interp_c<T, -1, true> : k_interp_c<T, -1, false>;
+    if constexpr (sizeof(T) == 8) {
+        if (q.stage) kern = pd == 1 ? k_interp_c<T, 1, true> : pd == 2 ? k_interp_c<T, 2, true> : pd == 3 ? k_interp_c<T, 3, true> : kern;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((a->n_rows + q.rb - 1) / q.rb)), dim3(SU_THREADS), smem, (hipStream_t)stream, q);
     return launch_status("k_interp_c");
 }
 

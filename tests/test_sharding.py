@@ -7,7 +7,6 @@ import sys
 
 import numpy
 import pytest
-import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 

@@ -2,7 +2,6 @@
 fixture for it.  CPU part: the oracle (NumPy + scipy.optimize.brentq, as the reference) does what the algorithm
 promises, and the scalar restatements of brentq / ndarray.sum() that the HIP kernel re-implements equal the
 library routines bit for bit.  GPU part (-m gpu): the kernel against the oracle."""
-import math
 
 import numpy
 import pytest

@@ -209,3 +209,51 @@ def test_float32_engine_runs_the_helpers():
     assert numpy.array_equal(idx, numpy.stack([numpy.searchsorted(xp[r], x[r], side="right") for r in range(50)]))
     p = torch.from_numpy(rng.uniform(1e4, 1.05e5, size=1000).astype(numpy.float32)).cuda()
     assert numpy.allclose(eng.exner(p).cpu().numpy(), orc.exner(p.cpu().numpy().astype(float)), rtol=2e-6)
+
+
+def test_fuzz_random_shapes_sharing_and_pitches(sputils):
+    """random row counts, sample / query lengths, shared vs per-row arrays and padded row pitches (device tensors that are
+    column slices of wider buffers) against NumPy / the oracle; SPC_FUZZ_TRIALS raises the trial count"""
+    from sp_coupler_amd import spcpl
+    eng = spcpl.get_engine()
+    trials = int(os.environ.get("SPC_FUZZ_TRIALS", "60"))
+    rng = numpy.random.default_rng(int(os.environ.get("SPC_FUZZ_SEED", "4242")))
+
+    def padded(a):
+        """the same values as a device tensor whose rows are `pad` elements apart more than they need be"""
+        if a.ndim == 1 or rng.random() < 0.5:
+            return torch.from_numpy(numpy.ascontiguousarray(a)).cuda()
+        pad = int(rng.integers(1, 9))
+        buf = torch.full((a.shape[0], a.shape[1] + pad), float("nan"), dtype=torch.float64, device="cuda")
+        buf[:, :a.shape[1]] = torch.from_numpy(numpy.ascontiguousarray(a)).cuda()
+        return buf[:, :a.shape[1]]
+
+    for t in range(trials):
+        n, n_xp, n_x = int(rng.integers(1, 70)), int(rng.integers(1, 300)), int(rng.integers(1, 200))
+        xp = numpy.sort(rng.uniform(0, 1e4, size=(n, n_xp)), axis=1)
+        fp = rng.normal(size=(n, n_xp))
+        x = rng.uniform(-100, 1.01e4, size=(n, n_x))
+        if n_xp > 2 and rng.random() < 0.3:
+            x[:, 0] = xp[:, n_xp // 2]
+        xs, xps = rng.random() < 0.3, rng.random() < 0.3
+        xa, xpa = (x[0] if xs else x), (xp[0] if xps else xp)
+        got = eng.interp(padded(xa), padded(xpa), padded(fp)).cpu().numpy()
+        assert_bits("fuzz interp %d" % t, got, _interp_rows(xa, xpa, fp))
+        side = "left" if rng.random() < 0.5 else "right"
+        gi = eng.searchsorted(padded(xpa), padded(xa), side=side).cpu().numpy()
+        wi = numpy.stack([numpy.searchsorted(xpa if xps else xpa[r], xa if xs else xa[r], side=side) for r in range(n)])
+        assert numpy.array_equal(gi, wi[0] if (xs and xps) else wi), ("fuzz searchsorted", t)      # two 1-D arguments: one row
+        # conservative coarsening: coarse bounds descending from above the fine grid's top down to its bottom
+        nL, nG = int(rng.integers(2, 400)), int(rng.integers(1, 60))
+        zh = numpy.cumsum(rng.uniform(0.5, 30, size=(n, nL)), axis=1)
+        zsh = rng.random() < 0.4
+        za = zh[0] if zsh else zh
+        top = (za[-1] if zsh else za[:, -1:]) * rng.uniform(0.6, 1.5)
+        bot = (za[0] if zsh else za[:, :1])
+        Zh = numpy.sort(rng.uniform(0, 1, size=(n, nG + 1)), axis=1)[:, ::-1] * (top - bot) + bot
+        Zh[:, -1] = bot if zsh else bot[:, 0]
+        q, rho = rng.normal(size=(n, nL)), rng.uniform(0.4, 1.3, size=(n, nL))
+        with numpy.errstate(all="ignore"):
+            want = numpy.stack([orc.interp_c(Zh[r], za if zsh else za[r], q[r], rho[r]) for r in range(n)])
+        got = eng.interp_c(padded(numpy.ascontiguousarray(Zh)), padded(za), padded(q), padded(rho)).cpu().numpy()
+        assert_bits("fuzz interp_c %d" % t, got, want)

@@ -889,14 +889,14 @@ int validate(const spc_dims *d)
 }
 
 // LDS elements per column / per block for each pass (pass 0 fwd, 1 bwd, 2 idx, 3 diag)
-void lds_elems(const spc_dims *d, int pass, bool with_idx, size_t *per_col, size_t *fixed)
+void lds_elems(const spc_dims *d, int pass, bool with_idx, size_t *per_col, size_t *fixed, size_t esize = 8)
 {
     const size_t nG = d->nG, nL = d->nL;
     const bool sh = d->les_grid_shared != 0;
     switch (pass) {
     case 0: *per_col = 6 * nG + ((with_idx && !sh) ? nL : 0); *fixed = (with_idx && sh) ? nL : 0; break;
     case 1: *per_col = 6 * nL + nG + (sh ? 0 : nL); *fixed = sh ? nL : 0; break;
-    case 4: *per_col = 7 * (nL + 1) + 13 * nG + 1 + (sh ? 0 : 2 * nL); *fixed = sh ? 2 * nL : 0; break;
+    case 4: *per_col = 7 * (nL + 1) + 8 * nG + 2 + (nG * 4 + esize - 1) / esize + 1 + (sh ? 0 : nL); *fixed = sh ? nL : 0; break;   // spc_k4.hpp; + zf[nL-1] per column
     case 2: *per_col = sh ? 0 : nL; *fixed = sh ? nL : 0; break;
     default: *per_col = 2 * nG; *fixed = 0; break;
     }
@@ -916,6 +916,7 @@ template <typename KernelT> int blocks_per_cu(KernelT kernel, size_t smem)
         const size_t by_lds = smem ? (size_t)(160 * 1024) / smem : 8;
         nb = (int)(by_lds < 4 ? by_lds : 4);
     }
+    if (getenv("SPC_DEBUG_OCC")) fprintf(stderr, "spc: occupancy query: %zu B of dynamic LDS -> %d workgroups per CU\n", smem, nb);
     if (nb > 8) nb = 8;
     cache[key] = nb;
     return nb;
@@ -932,7 +933,7 @@ template <typename KernelT> int blocks_per_cu(KernelT kernel, size_t smem)
 template <typename KernelT> int pick_cb(const spc_dims *d, int pass, bool with_idx, size_t esize, KernelT kernel)
 {
     size_t per_col, fixed;
-    lds_elems(d, pass, with_idx, &per_col, &fixed);
+    lds_elems(d, pass, with_idx, &per_col, &fixed, esize);
     int cb = d->cols_per_block;
     if (cb > 0) {
         while (cb > 1 && (per_col * cb + fixed) * esize > (size_t)MAX_LDS_BYTES) --cb;
@@ -1229,7 +1230,7 @@ template <typename T> int choose_bwd(const spc_dims *d, bool cons, Choice *c)
     c->cb = sb ? sb : (cons ? pick_cb(d, 4, false, sizeof(T), cons_kernel<T>(c->geo, cons_depth(d->nL)))
                             : pick_cb(d, 1, false, sizeof(T), bwd_kernel<T>(c->geo, 0, BLOCK, c->pre)));
     size_t per_col, fixed;
-    lds_elems(d, cons ? 4 : 1, false, &per_col, &fixed);
+    lds_elems(d, cons ? 4 : 1, false, &per_col, &fixed, sizeof(T));
     c->smem = (per_col * c->cb + fixed) * sizeof(T);
     c->grid = (unsigned)((d->n_cols + c->cb - 1) / c->cb);
     return SPC_OK;

@@ -8,14 +8,20 @@
 // accumulators, 8192-element chunks), so any nL is supported and results stay bit-identical to the NumPy
 // evaluation.  LDS per column: q[7][nL+1] = t | qt | ql | ql_ice | u | v | rho (one element of padding per
 // field: a field stride of nL x 8 B = 0 mod 64 banks would put the eight lanes of a level on one bank), then
-// Zf[nG] | Zh[nG+1] | X[7][nG] (layer means) | cell range ia, ib and edge pieces da, db per level [4][nG]; then zf and zh ([nL] each when shared, else [CB x nL] each).
-// Round 3 built and measured four other forms of this kernel at config 3 (profiles/r03_k4_forms.log), all SLOWER than
-// this one with two columns per workgroup (223 us): a compacted list of the (column, level) pairs that have cells
-// (255 us); one thread per (tendency, level) with the level running fastest, every thread repeating the weight sum,
-// no layer means in LDS (366 us); the eight lanes of a level storing their own tendency -- 64-byte segments per array,
-// one phase and 5 KB of LDS less (259-282 us); and this form on 15.6 instead of 19 KB of LDS per column (edge pieces
-// recomputed, Zf overlaid, zf not staged), which costs 6 VGPRs and with them the fifth wave per SIMD (232 us; 276 us
-// when the fifth wave is bought with spills).  K4 is bound by the dependent LDS reads of its searches and sums.
+// Zh[nG+1] | X[7][nG] (layer means; its first nG elements hold Zf until start_index has been taken from them) | the
+// cell range (ia, ib) of every level as two int16 in one word | start_index; then zh ([nL] when shared, else [CB x nL])
+// and the LES top zf[nL-1] per column.
+// K4's workgroups live as long as K3's (their loads queue in a saturated memory system), so its rate follows the
+// number of RESIDENT COLUMNS per CU, which LDS caps: round 3 first went from one to two columns per workgroup (5 -> 8
+// columns per CU: 250 -> 223 us at config 3), then cut the footprint from 19 to 15.2 KB per column -- the edge pieces
+// da, db are recomputed by the lanes AFTER their sums (before them they cost the 6 VGPRs that separate five waves per
+// SIMD from four), Zf shares the layer means' space, zf is not staged, (ia, ib) are packed -- so that a two-column
+// workgroup needs 31 744 B = 25 of gfx950's 1 280-byte LDS allocation granules and FIVE of them fit a CU (32 464 B,
+// one granule more, still gave four): 223 -> 196 us, 1.48 x K3.
+// Other forms built and measured slower in round 3 (profiles/r03_k4_forms.log): a compacted list of the (column, level)
+// pairs that have cells (255 us); one thread per (tendency, level) with the level running fastest, every thread
+// repeating the searches and the weight sum, no layer means in LDS (366 us); the eight lanes of a level storing their
+// own tendency -- 64-byte segments per array (259-282 us); the fifth wave bought with spilled registers (276 us).
 #pragma once
 
 // numpy's pairwise recursion with its depth fixed at compile time (no stack, no scratch memory): for the compile-time
@@ -48,13 +54,15 @@ template <typename T, int NG = 0, int NL = 0, int PD = -1> __global__ __launch_b
     const int64_t pitchG = NG ? NG : d.pitchG, pitchGh = NG ? NG + 1 : d.pitchGh, pitchL = NL ? NL : d.pitchL;
     const int64_t col0 = (int64_t)slab_index(d.xcd_remap) * cb;
     const int ncol = (int)((d.n_cols - col0) < cb ? (d.n_cols - col0) : cb);
-    const size_t per_col = (size_t)7 * nLp + nG + (nG + 1) + (size_t)7 * nG + (size_t)4 * nG;   // + cell ranges / edge pieces per level
+    constexpr int IPE = sizeof(T) / sizeof(int);                 // ints per element
+    const size_t o_Zh = (size_t)7 * nLp, o_X = o_Zh + nG + 1, o_cell = o_X + (size_t)7 * nG;
+    const size_t o_sidx = o_cell + (size_t)(nG + IPE - 1) / IPE, per_col = o_sidx + 1;
     T *const lds = reinterpret_cast<T *>(spc_smem);
-    T *const lh = lds + (size_t)cb * per_col;                    // zf
-    T *const lzh = lh + (d.shared_grid ? nL : (size_t)cb * nL);  // zh
+    T *const lzh = lds + (size_t)cb * per_col;                       // zh
+    T *const ltop = lzh + (d.shared_grid ? nL : (size_t)cb * nL);    // zf[nL-1] per column
     const int n1 = ncol * nG;
 
-    // ---- stage the LES slab, the LES grids and the GCM heights ------------------------------------------------
+    // ---- stage the LES slab, the LES half levels and the GCM heights --------------------------------------------
     for (int e = tid; e < ncol * nL; e += BLOCK) {
         const int c = e / nL, l = e - c * nL;
         const int64_t o = (col0 + c) * pitchL + l;
@@ -66,34 +74,40 @@ template <typename T, int NG = 0, int NL = 0, int PD = -1> __global__ __launch_b
         s[4 * nLp] = p.u_d[o];
         s[5 * nLp] = p.v_d[o];
         s[6 * nLp] = p.rhobf_d[o];
-        if (!d.shared_grid) { lh[e] = p.zf[o]; lzh[e] = p.zh[o]; }
+        if (!d.shared_grid) lzh[e] = p.zh[o];
     }
     if (d.shared_grid)
-        for (int e = tid; e < nL; e += BLOCK) { lh[e] = p.zf[e]; lzh[e] = p.zh[e]; }
+        for (int e = tid; e < nL; e += BLOCK) lzh[e] = p.zh[e];
     for (int e = tid; e < ncol * (nG + 1); e += BLOCK) {
         const int c = e / (nG + 1), k = e - c * (nG + 1);
         const int64_t col = col0 + c, gh = col * pitchGh;
-        T *const s = lds + (size_t)c * per_col + 7 * nLp;
-        s[nG + k] = p.Zh ? p.Zh[gh + k] : div_grav(p.Zghalf[gh + k] - p.Zghalf[gh + nG]);      // spcpl.py:197
+        T *const s = lds + (size_t)c * per_col;
+        s[o_Zh + k] = p.Zh ? p.Zh[gh + k] : div_grav(p.Zghalf[gh + k] - p.Zghalf[gh + nG]);    // spcpl.py:197
         if (k < nG) {
             const int64_t g = col * pitchG + k;
-            s[k] = p.Zf ? p.Zf[g] : div_grav(p.Zgfull[g] - p.Zghalf[gh + nG]);                  // spcpl.py:198
+            s[o_X + k] = p.Zf ? p.Zf[g] : div_grav(p.Zgfull[g] - p.Zghalf[gh + nG]);           // Zf, spcpl.py:198 (until phase 3)
+        } else {
+            ltop[c] = p.zf[d.shared_grid ? (int64_t)(nL - 1) : col * pitchL + (nL - 1)];        // h[-1] of spcpl.py:498
         }
     }
     __syncthreads();
 
     // ---- per GCM level, once: which LES cells the layer [Zh[k+1], Zh[k]] covers (the scans of integral(), sputils.py:
     //      113-127).  ia < 0 encodes the two special outcomes: -1 layer above the LES top (Q stays 0, sputils.py:187),
-    //      -2 an end point outside zh (integral returns None -> NaN).
-    for (int e = tid; e < n1; e += BLOCK) {
+    //      -2 an end point outside zh (integral returns None -> NaN); ib < 0 encodes sign = -1 (sputils.py:117-120).
+    //      One more thread per column: start_index, from Zf where the layer means will be.
+    for (int e = tid; e < n1 + ncol; e += BLOCK) {
+        if (e >= n1) {
+            T *const s = lds + (size_t)(e - n1) * per_col;
+            reinterpret_cast<int *>(s + o_sidx)[0] = ss_left_neg(s + o_X, nG, ltop[e - n1]);     // spcpl.py:498
+            continue;
+        }
         const int c = e / nG, k = e - c * nG;
         T *const s = lds + (size_t)c * per_col;
         const T *const z = d.shared_grid ? lzh : lzh + (size_t)c * nL;
-        const T *const Zh = s + 7 * nLp + nG;
-        int *const cell = reinterpret_cast<int *>(s + 7 * nLp + nG + (nG + 1) + (size_t)7 * nG);      // ia[nG] | ib[nG] (ints in 2 nG elements)
-        T *const edge = s + 7 * nLp + nG + (nG + 1) + (size_t)7 * nG + 2 * nG;                        // da[nG] | db[nG]
+        const T *const Zh = s + o_Zh;
+        int *const cell = reinterpret_cast<int *>(s + o_cell);                         // (ia, ib) as two int16 in one word per level
         int ia = -1, ib = -1;
-        T da = T(0), db = T(0);
         if (Zh[k] < z[nL - 1]) {                                                       // sputils.py:187
             T a = Zh[k + 1], b = Zh[k];                                                // integral(ZZ[i+1], ZZ[i], ...)
             if (a < z[0] || a > z[nL - 1] || b < z[0] || b > z[nL - 1]) {
@@ -104,12 +118,10 @@ template <typename T, int NG = 0, int NL = 0, int PD = -1> __global__ __launch_b
                 ia = scan_cell(z, nL, a);                                              // sputils.py:122-124
                 ib = scan_cell(z, nL, b);                                              // sputils.py:125-127
                 if (ib < ia) ib = ia;
-                da = a - z[ia]; db = z[ib + 1] - b;
-                if (swap) ib = -ib - 2;                                                // sign = -1 encoded in ib < 0
+                if (swap) ib = -ib - 2;
             }
         }
-        cell[k] = ia; cell[nG + k] = ib;
-        edge[k] = da; edge[nG + k] = db;
+        cell[k] = (ia & 0xffff) | (ib * 65536);       // |ia|, |ib| < 2^15: an LES column of that height would not fit the LDS
     }
     __syncthreads();
 
@@ -119,18 +131,17 @@ template <typename T, int NG = 0, int NL = 0, int PD = -1> __global__ __launch_b
         T *const s = lds + (size_t)c * per_col;
         const T *const z = d.shared_grid ? lzh : lzh + (size_t)c * nL;
         const T *const w = s + 6 * nLp;
-        const int *const cell = reinterpret_cast<const int *>(s + 7 * nLp + nG + (nG + 1) + (size_t)7 * nG);
-        const T *const edge = s + 7 * nLp + nG + (nG + 1) + (size_t)7 * nG + 2 * nG;
-        const int ia = cell[k];
+        const int *const cell = reinterpret_cast<const int *>(s + o_cell);
+        const int pk = cell[k], ia = (int)(short)(pk & 0xffff);
         T X = T(0);                                                                    // Q = zeros (sputils.py:185)
         if (ia == -2) {
             X = T(0) / T(0);           // Q[i] = None stores NaN (numpy 2.x)
         } else if (ia >= 0) {
-            int ib = cell[nG + k];
-            T sign = T(1);
-            if (ib < 0) { ib = -ib - 2; sign = T(-1); }
+            int ib = pk >> 16;
+            const bool swap = ib < 0;
+            if (swap) ib = -ib - 2;
+            const T sign = swap ? T(-1) : T(1);
             const int cnt = ib - ia + 1;
-            const T da = edge[k], db = edge[nG + k];
             // fields in the order of spcpl.py:482-488: t, qt, ql, ql_water (= ql - ql_ice, :402), ql_ice, u, v
             const T *const qa = s + (size_t)(f < 3 ? f : (f < 7 ? f - 1 : 0)) * nLp;
             const T *const qb = s + (size_t)3 * nLp;
@@ -144,13 +155,16 @@ template <typename T, int NG = 0, int NL = 0, int PD = -1> __global__ __launch_b
             if constexpr (NL != 0) S = T(0) + vn_pw<vn_pw_depth(NL)>(term, 0, cnt);         // cnt <= NL <= 8192: one chunk
             else if constexpr (PD >= 0) S = T(0) + vn_pw<PD>(term, 0, cnt);                 // cnt <= nL, depth checked by the host
             else S = cnt <= 128 ? T(0) + vn_leaf(term, 0, cnt) : vn_npsum(term, cnt);
+            // the edge pieces, only now: they are not live during the sums (4 VGPRs: the fifth wave per SIMD)
+            const T za = s[o_Zh + k + 1], zb = s[o_Zh + k];                            // a, b of integral() before the swap
+            const T da = (swap ? zb : za) - z[ia], db = z[ib + 1] - (swap ? za : zb);  // sputils.py:154,159
             const T ea = wsum ? w[ia] * da : (w[ia] * q(ia)) * da;                     // Sa / Swa, sputils.py:154,159
             const T eb = wsum ? w[ib] * db : (w[ib] * q(ib)) * db;                     // Sb / Swb
             const T num = (S - ea) - eb;
             const T den = __shfl(num, (threadIdx.x & 63) | 7);                         // the level's weight lane
             X = num / den * sign;                                                      // sputils.py:161
         }
-        if (f < 7) s[7 * nLp + nG + (nG + 1) + (size_t)f * nG + k] = X;
+        if (f < 7) s[o_X + (size_t)f * nG + k] = X;
     }
     __syncthreads();
 
@@ -159,10 +173,9 @@ template <typename T, int NG = 0, int NL = 0, int PD = -1> __global__ __launch_b
         const int c = e / nG, k = e - c * nG;
         const int64_t col = col0 + c, cg = col * pitchG, g = cg + k;
         const T *const s = lds + (size_t)c * per_col;
-        const T *const h = d.shared_grid ? lh : lh + (size_t)c * nL;
-        const T *const Zf = s + 7 * nLp, *const X = Zf + nG + (nG + 1);
+        const T *const X = s + o_X;
         const GcmIn<T> in = load_gcm(p, g, cg + (nG - 1 - k));
-        const int start_index = ss_left_neg(Zf, nG, h[nL - 1]);                        // spcpl.py:498
+        const int start_index = reinterpret_cast<const int *>(s + o_sidx)[0];
         const T X0 = X[k], X1 = X[nG + k], X2 = X[2 * nG + k], X3 = X[3 * nG + k], X4 = X[4 * nG + k], X5 = X[5 * nG + k],
                 X6 = X[6 * nG + k];
         T f_T = p.factor * (X0 - in.tt) / p.dt;                                        // spcpl.py:518

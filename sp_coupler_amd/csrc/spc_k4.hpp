@@ -17,7 +17,7 @@
 // da, db are recomputed by the lanes AFTER their sums (before them they cost the 6 VGPRs that separate five waves per
 // SIMD from four), Zf shares the layer means' space, zf is not staged, (ia, ib) are packed -- so that a two-column
 // workgroup needs 31 744 B = 25 of gfx950's 1 280-byte LDS allocation granules and FIVE of them fit a CU (32 464 B,
-// one granule more, still gave four): 223 -> 196 us, 1.48 x K3.
+// one granule more, still gave four): 223 -> 194-196 us, 1.48-1.51 x K3.
 // Other forms built and measured slower in round 3 (profiles/r03_k4_forms.log): a compacted list of the (column, level)
 // pairs that have cells (255 us); one thread per (tendency, level) with the level running fastest, every thread
 // repeating the searches and the weight sum, no layer means in LDS (366 us); the eight lanes of a level storing their

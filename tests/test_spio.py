@@ -1,4 +1,6 @@
 """CPU test of the spifs writer: schema of splib/spio.py, f4 storage, batched writes."""
+import os
+
 import numpy
 
 from sp_coupler_amd import spio
@@ -34,3 +36,19 @@ def test_writer_roundtrip(tmp_path):
         assert False
     except KeyError:
         pass
+
+
+def test_example_reader_prints_a_column(tmp_path):
+    """examples/access_spifs.py, the counterpart of the reference's examples/access-spifs-nc.py for the batched layout"""
+    import subprocess
+    import sys
+    path = str(tmp_path / "spifs.nc")
+    w = spio.SpifsWriter(path, [5, 9], [1.0, 2.0], [3.0, 4.0], numpy.arange(4.) * 25, 3)
+    w.update_time(900.0)
+    w.write(Zf=numpy.full((2, 3), 100.), T=numpy.full((2, 3), 280.), SH=numpy.full((2, 3), 0.01), U=numpy.ones((2, 3)),
+            V=numpy.ones((2, 3)))
+    w.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "access_spifs.py"), path, "1"], capture_output=True,
+                         text=True, check=True).stdout
+    assert "grid_index 9" in out and out.count("100.0 280.0 0.0100") == 3

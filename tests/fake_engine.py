@@ -60,6 +60,49 @@ class OracleEngine:
         from sp_coupler_amd.transfer import Arena
         return Arena(self.device, specs)
 
+    # -- the K7 operators (Engine.exner / interp / searchsorted / interp_c / rms) row by row through the oracle ----------
+    @staticmethod
+    def _rows(*ts):
+        n = max(int(t.shape[0]) if t.dim() == 2 else 1 for t in ts)
+        return n, [(lambda r, a=t.numpy(): a[r] if a.ndim == 2 else a) for t in ts]
+
+    def exner(self, p, inverse=False, stream=None):
+        return torch.from_numpy(numpy.asarray((orc.iexner if inverse else orc.exner)(p.numpy())))
+
+    def interp(self, x, xp, fp, stream=None):
+        if xp.shape[-1] != fp.shape[-1]:
+            raise ValueError("fp and xp are not of the same length")
+        n, (gx, gxp, gfp) = self._rows(x, xp, fp)
+        with numpy.errstate(all="ignore"):
+            out = numpy.stack([numpy.interp(gx(r), gxp(r), gfp(r)) for r in range(n)])
+        return torch.from_numpy(out[0] if x.dim() == xp.dim() == fp.dim() == 1 else out)
+
+    def searchsorted(self, a, v, side="left", stream=None):
+        n, (ga, gv) = self._rows(a, v)
+        out = numpy.stack([numpy.searchsorted(ga(r), gv(r), side=side) for r in range(n)]).astype(numpy.int64)
+        return torch.from_numpy(out[0] if a.dim() == v.dim() == 1 else out)
+
+    def interp_c(self, Zh, zh, q, rho=None, mode="interp_c", stream=None):
+        n, (gZ, gz, gq) = self._rows(Zh, zh, q)
+        gr = self._rows(rho)[1][0] if rho is not None else None
+        rows = []
+        with numpy.errstate(all="ignore"):
+            for r in range(n):
+                if mode == "interp_c":
+                    rows.append(orc.interp_c(gZ(r), gz(r), gq(r), gr(r)))
+                elif mode == "interp_rho":
+                    rows.append(orc.interp_rho(gZ(r), gz(r), gq(r)))
+                else:
+                    Z = gZ(r)
+                    vals = [orc.integral(Z[k + 1], Z[k], gz(r), gq(r), gr(r) if gr else None) for k in range(len(Z) - 1)]
+                    rows.append(numpy.array([numpy.nan if v is None else v for v in vals], dtype=numpy.float64))
+        out = numpy.stack(rows)
+        return torch.from_numpy(out[0] if Zh.dim() == q.dim() == 1 else out)
+
+    def rms(self, a, stream=None):
+        x = a.numpy()
+        return torch.from_numpy(numpy.asarray(orc.rms(x) if x.ndim == 1 else numpy.array([orc.rms(r) for r in x])))
+
     def to_devices(self, host_array, rows=None, n_cols=None):
         return torch.from_numpy(numpy.ascontiguousarray(host_array)).to(self.device, self.dtype)
 

@@ -16,9 +16,10 @@ from tools import spc_tools  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 rot = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+with_k4 = len(sys.argv) > 3 and sys.argv[3] == "k4"        # also the conservative backward (K4) on the same batches
 eng = Engine("cuda:0")
 sptr = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-fpl, bpl = [], []
+fpl, bpl, cpl = [], [], []
 for r in range(rot):
     gcm, zf, zh, prof = synthetic.make_batch_tiled(n, 91, 160, seed=500 + r, couple_surface=False)
     g = {k: torch.from_numpy(v).cuda() for k, v in gcm.items()}
@@ -27,6 +28,8 @@ for r in range(rot):
     fp, bp = eng.plan_exchange(g, zf_d, zh_d, p, 1.0, 1.0, 900.0)      # exactly what bench.py times
     fpl.append(fp)
     bpl.append(bp)
+    if with_k4:
+        cpl.append(eng.plan_backward(g, zf_d, p, 1.0, 900.0, Zf=None, want_start_index=False, conservative=True, zh=zh_d))
 src = torch.empty(1 << 28, dtype=torch.uint8, device="cuda").random_(0, 255)      # 256 MiB
 dst = torch.empty_like(src)
 torch.cuda.synchronize()
@@ -36,5 +39,7 @@ for it in range(3):
 for i in range(3 * rot):
     fpl[i % rot].launch_raw(sptr)
     bpl[i % rot].launch_raw(sptr)
+    if with_k4:
+        cpl[i % rot].launch_raw(sptr)
 torch.cuda.synchronize()
 print("pmc workload done: n=%d rot=%d copy_bytes=%d" % (n, rot, src.numel()))

@@ -115,6 +115,9 @@ def test_describe_launch_names_the_instantiation_the_launcher_would_pick(lib):
     full = _abi.describe_launch(lib, d(4096), 0, 3)
     assert full.startswith("k_forward<f64,full,91,160,wt=0,blk=256,pre=0> cb=")        # FULL: plain stores only
     assert _abi.describe_launch(lib, d(4096), 4, 0).startswith("k_backward_cons2<f64,91,160> cb=")
+    # K4's footprint is what lets FIVE two-column workgroups share a CU: 25 of gfx950's 1 280-byte LDS allocation granules
+    k4 = _abi.describe_launch(lib, d(35718), 4, 0)
+    assert " cb=2 " in k4 and int(k4.split("lds=")[1]) <= 25 * 1280, k4
     assert _abi.describe_launch(lib, d(4096, nL=400), 4, 0).startswith("k_backward_cons2<f64,0,0,pd=2> cb=")
     assert _abi.describe_launch(lib, d(4096, nL=2000), 4, 0).startswith("k_backward_cons2<f64,0,0,pd=-1> cb=")
     assert _abi.describe_launch(lib, d(4096), 0, 1, 4).startswith("k_forward<f32,lean,91,160,")

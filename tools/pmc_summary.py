@@ -46,7 +46,7 @@ def main():
             ks[k]["write_counter_over_true"] = ks[k].get("WRITE_SIZE_KiB_avg", 0) * 1024 / copy_bytes
     res["calibration"] = {}
     # both first-generation kernels access 8 B per lane (PMC_CAL_K1=k_copy16 when a 16-B second-generation K1 is forced)
-    for k, calk in (("k_forward", os.environ.get("PMC_CAL_K1", "k_copy8")), ("k_backward", "k_copy8")):
+    for k, calk in (("k_forward", os.environ.get("PMC_CAL_K1", "k_copy8")), ("k_backward", "k_copy8"), ("k_backward_cons", "k_copy8")):
         cal = ks.get(calk, {})
         fr, wr = cal.get("fetch_counter_over_true", 0.5), cal.get("write_counter_over_true", 1.0)
         res["calibration"][k] = {"pattern": calk, "fetch_counter_over_true": fr, "write_counter_over_true": wr}
@@ -59,6 +59,8 @@ def main():
             ks[k]["hbm_bytes_per_column"] = (f + w) / n_cols
     res["k_forward_bytes_per_launch"] = ks.get("k_forward", {}).get("hbm_bytes_per_launch")
     res["k_backward_bytes_per_launch"] = ks.get("k_backward", {}).get("hbm_bytes_per_launch")
+    if "k_backward_cons" in ks:
+        res["k_backward_cons_bytes_per_launch"] = ks["k_backward_cons"].get("hbm_bytes_per_launch")
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

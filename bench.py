@@ -131,26 +131,28 @@ def cpu_baseline_multicore(gcm, zf, zh, prof, budget_s, workers):
             "sample": "%d column-exchanges in %d processes x %.1f s (NumPy per-column loop)" % (total, len(res), wall)}
 
 
-def verify(fplan, bplan, ref_f, ref_b, n_ref, factor, dt):
-    """Outputs of batch 0 (left in HBM by the timed launches) against the oracle outputs of the cpu_baseline
-    leg: index map and everything not downstream of pow() bit-exact; f_thl within 8 ulp of thl's scale / dt."""
+def compare_with_oracle(F, B, ref_f, ref_b, factor, dt):
+    """HIP outputs (dicts of host arrays) against oracle outputs of the same rows: index map and everything not
+    downstream of pow() bit-exact (incl. the sign of zero and NaN positions); f_thl within 8 ulp of thl's scale / dt.
+    Returns (list of failures, f_thl statistics)."""
     import numpy
     eps = 2.220446049250313e-16
     bad = []
 
     def bits(name, got, want):
-        got, want = got[:n_ref], want[:n_ref]
+        if got.shape != want.shape:
+            bad.append("%s: shape %s vs %s" % (name, got.shape, want.shape))
+            return
         same = (got == want) | (numpy.isnan(got) & numpy.isnan(want))
         if not same.all() or not numpy.array_equal(numpy.signbit(got)[~numpy.isnan(want)], numpy.signbit(want)[~numpy.isnan(want)]):
             bad.append("%s: %d elements differ" % (name, int((~same).sum())))
-    F = {k: v.cpu().numpy() for k, v in fplan.outputs.items()}
-    B = {k: v.cpu().numpy() for k, v in bplan.outputs.items()}
-    bits("idx", F["idx"], ref_f["idx"].astype(F["idx"].dtype))
+    if "idx" in F:
+        bits("idx", F["idx"], ref_f["idx"].astype(F["idx"].dtype))
     for k in ("f_u", "f_v", "f_qt", "f_ql", "ql_ref", "f_ps"):
         bits(k, F[k], ref_f[k])
     for k in ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A"):
         bits(k, B[k], ref_b[k])
-    err = float(numpy.abs(F["f_thl"][:n_ref] - ref_f["f_thl"]).max())
+    err = float(numpy.abs(F["f_thl"] - ref_f["f_thl"]).max())
     bound = 8 * eps * float(numpy.abs(ref_f["thl"]).max()) * abs(factor) / dt
     if not err <= bound:
         bad.append("f_thl: max abs err %.3e > %.3e" % (err, bound))
@@ -158,7 +160,7 @@ def verify(fplan, bplan, ref_f, ref_b, n_ref, factor, dt):
     # element-wise view of the same comparison: f_thl = factor (thl - thl_d) / dt cancels, so an element whose forcing is
     # tiny carries the absolute error of thl (<= 8 ulp of ~300 K, / dt) on a small value; the two CPU oracles (NumPy / C)
     # differ from each other by 4 ulp of thl (tests/test_oracle.py), so no tighter element-wise bar is definable
-    d = numpy.abs(F["f_thl"][:n_ref] - ref_f["f_thl"])
+    d = numpy.abs(F["f_thl"] - ref_f["f_thl"])
     a = numpy.abs(ref_f["f_thl"])
     nz = a > 0
     erel = d[nz] / a[nz]
@@ -167,8 +169,168 @@ def verify(fplan, bplan, ref_f, ref_b, n_ref, factor, dt):
           "fraction_of_elements_above_1e-10_relative": float((erel > 1e-10).mean()) if erel.size else 0.0,
           "smallest_abs_f_thl_among_those": float(a[nz][erel > 1e-10].min()) if (erel > 1e-10).any() else None,
           "max_rel_err_where_abs_f_thl_ge_1e-5": float((d[a >= 1e-5] / a[a >= 1e-5]).max()) if (a >= 1e-5).any() else None}
-    return (not bad), {"columns_checked": int(n_ref), "bit_exact": "idx,f_u,f_v,f_qt,f_ql,ql_ref,f_ps,f_T,f_SH,f_QL,f_QI,f_U,f_V,f_A",
-                       "f_thl_max_rel_err": rel, "f_thl_elementwise": ew, "failures": bad}
+    return bad, {"f_thl_max_rel_err": rel, "f_thl_elementwise": ew}
+
+
+BIT_EXACT = "idx,f_u,f_v,f_qt,f_ql,ql_ref,f_ps,f_T,f_SH,f_QL,f_QI,f_U,f_V,f_A"
+
+
+def verify(fplan, bplan, ref_f, ref_b, n_ref, factor, dt):
+    """Outputs of batch 0 (left in HBM by the timed launches) against the oracle outputs of the cpu_baseline
+    leg (the first ``n_ref`` columns)."""
+    F = {k: v.cpu().numpy()[:n_ref] for k, v in fplan.outputs.items()}
+    B = {k: v.cpu().numpy()[:n_ref] for k, v in bplan.outputs.items()}
+    bad, det = compare_with_oracle(F, B, ref_f, ref_b, factor, dt)
+    return (not bad), dict(det, columns_checked=int(n_ref), bit_exact=BIT_EXACT, failures=bad)
+
+
+def sample_rows(n, m=4096):
+    """row numbers of a check sample of (at most) m rows of an n-row block: its first and last m/3 rows and m/3 rows
+    spread evenly over the rest -- always including row 0 and row n - 1"""
+    import numpy
+    if n <= m:
+        return numpy.arange(n, dtype=numpy.int64)
+    a = m // 3
+    mid = numpy.linspace(a, n - a - 1, m - 2 * a).astype(numpy.int64)
+    return numpy.unique(numpy.concatenate([numpy.arange(a), mid, numpy.arange(n - a, n)]))
+
+
+def sample_check(fout, bout, g, p, zf, zh, factor, dt, m=4096):
+    """A sample of the rows of one device's block (``sample_rows``): the inputs the kernels read are fetched FROM THE
+    DEVICE, run through the plain-C oracle (tests/oracle_c.py: oracle/spc_oracle.c, the independent restatement with the
+    ABI's own argument structs) on the host, and compared with the outputs the timed plans left in HBM.  ``fout`` /
+    ``bout``: output dicts of the forward / backward plan; ``g`` / ``p``: the device tensors the plans were built on.
+    Used where no CPU copy of the batch exists: the ranks of an N > 1 run, the devices of in_process_all_gpus."""
+    import numpy
+    import torch
+    from tests import oracle_c
+    n = int(g["T"].shape[0])
+    rows = sample_rows(n, m)
+    rt = torch.from_numpy(rows).to(g["T"].device)
+    take = lambda t: numpy.ascontiguousarray(t.index_select(0, rt).cpu().numpy())       # noqa: E731
+    gs = {k: take(v) for k, v in g.items() if k in ("U", "V", "T", "SH", "QL", "QI", "Pfull", "Phalf", "A", "Zgfull", "Zghalf")}
+    ps = {k: take(v) for k, v in p.items() if k in ("U", "V", "THL", "QT", "QL", "QL_ice", "T", "PS", "A")}
+    ps["Rain"], ps["rain_last"] = numpy.zeros(len(rows)), numpy.zeros(len(rows))
+    zfn, zhn = numpy.ascontiguousarray(zf.cpu().numpy()), numpy.ascontiguousarray(zh.cpu().numpy())
+    ref_f = oracle_c.forward(gs, zfn, zhn, ps, factor, dt, couple_surface=False)
+    ref_b = oracle_c.backward(gs, None, zfn, ps, factor, dt)
+    F = {k: take(v) for k, v in fout.items()}
+    B = {k: take(v) for k, v in bout.items()}
+    bad, det = compare_with_oracle(F, B, ref_f, ref_b, factor, dt)
+    return (not bad), {"rows_checked": int(len(rows)), "first_row": int(rows[0]), "last_row": int(rows[-1]), "rows_in_block": n,
+                       "oracle": "oracle/spc_oracle.c (plain C, glibc pow) on inputs read back from the device",
+                       "f_thl_max_rel_err": det["f_thl_max_rel_err"], "failures": bad}
+
+
+def device_identity(index):
+    """what a reader needs to tell N distinct GPUs from one GPU used N times"""
+    import torch
+    pr = torch.cuda.get_device_properties(index)
+    return {"index": int(index), "name": pr.name, "arch": getattr(pr, "gcnArchName", None),
+            "pci": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)),
+            "uuid": str(getattr(pr, "uuid", "")), "cus": int(pr.multi_processor_count), "hbm_GiB": round(pr.total_memory / 2 ** 30, 1)}
+
+
+def _bits_equal(a, b):
+    import numpy
+    a, b = numpy.asarray(a), numpy.asarray(b)
+    return a.shape == b.shape and bool(((a == b) | ((a != a) & (b != b))).all())
+
+
+def dropin_verify(cpl, gcm, ens, label):
+    """Is what the model objects RECEIVED through the drop-in step (after the uploads, the launches and the downloads of
+    whatever transport that batch size takes) what the kernels compute from what the models HANDED OVER?  Called straight
+    after the last timed Coupler.step of a batched-protocol leg:
+      uploads   the device copy of every array the GCM / LES stand-ins wrote into the pinned buffers == that buffer;
+      K3        the seven tendencies the GCM stand-in received == a synchronous recompute (Engine.backward on the same
+                device inputs, fresh output tensors, default stream, waited for) == the NumPy oracle on a row sample;
+      K1        one more (untimed) step: the forcings the LES ensemble receives == a synchronous Engine.forward on a
+                device snapshot of the slab means that step's K1 reads + that step's GCM state, == the oracle on a sample.
+    Bit for bit except f_thl against the oracle (8 ulp of thl / dt, as `verified`).  Returns (ok, detail)."""
+    import numpy
+    import torch
+    from oracle import spcpl_oracle as orc
+    from sp_coupler_amd import spcpl
+    from sp_coupler_amd.transfer import Sharded
+    b = spcpl.current_batch()
+    buf, eng, n = b.buf, b.engine, b.n
+    dt = float(gcm.get_timestep())
+    lf, gf = float(cpl.les_forcing_factor), float(cpl.gcm_forcing_factor)
+    sync = torch.cuda.synchronize if torch.cuda.is_available() else (lambda: None)
+    sync()
+    bad, checked = [], []
+    host = spcpl._to_host
+    rows = sample_rows(n, 192)
+    zf_h, zh_h = numpy.asarray(b.zf_host), numpy.asarray(b.zh_host)
+
+    def uploads(arena, names, what):
+        for k in names:
+            if not _bits_equal(host(arena.d[k])[:n], arena.hn[k][:n]):
+                bad.append("%s %s: device copy differs from the pinned host array" % (what, k))
+        checked.append("%s: %d arrays device == host" % (what, len(names)))
+    with eng.on_stream():
+        uploads(buf.gcm_in, spcpl.gcm_vars, "h2d_gcm")
+        uploads(buf.les_in, spcpl._BWD_KEYS + ("THL", "PS"), "h2d_les")
+        # K3 of the last timed step
+        r3 = eng.backward(b.gcm, b.zf, {k: buf.les_in.d[k] for k in spcpl._BWD_KEYS}, gf, dt, Zf=None)
+        got3 = {}
+        for var in spcpl._TEND_VARS:
+            rec = gcm.tendencies.get(var)
+            got3[var] = None if not isinstance(rec, tuple) else rec[1]
+            if got3[var] is None or not _bits_equal(got3[var], host(r3["f_" + var])):
+                bad.append("k3 f_%s: what the GCM received differs from the synchronous recompute" % var)
+        checked.append("k3: 7 tendencies x %d columns received == recompute" % n)
+    g_h = {v: numpy.ascontiguousarray(buf.gcm_in.hn[v][:n][rows]) for v in spcpl.gcm_vars}
+    p_h = {k: numpy.ascontiguousarray(buf.les_in.hn[k][rows]) for k in spcpl._BWD_KEYS + ("THL",)}
+    Zf = (g_h["Zgfull"] - g_h["Zghalf"][:, -1:]) / orc.grav
+    ref_b = orc.backward_batched(g_h, Zf, p_h, zf_h, gf, dt)
+    for var in spcpl._TEND_VARS:
+        if got3[var] is not None and not _bits_equal(got3[var][rows], ref_b["f_" + var]):
+            bad.append("k3 f_%s: differs from the oracle on the row sample" % var)
+    checked.append("k3: oracle on %d sample rows (first %d ... last %d)" % (len(rows), rows[0], rows[-1]))
+    # K1: the slab means the NEXT step's K1 reads are on the device now
+    fkeys = ("U", "V", "THL", "QT", "QL", "PS")
+    with eng.on_stream():
+        snap = {}
+        for k in fkeys:
+            t = buf.les_in.d[k]
+            snap[k] = Sharded([p_.clone() for p_ in t.parts], t.bounds) if isinstance(t, Sharded) else t.clone()
+        snap_h = {k: host(v) for k, v in snap.items()}
+    received = {}
+    orig = ens.set_forcings_batched
+
+    def tap(**arrays):
+        for k, v in arrays.items():
+            received[k] = numpy.array(v)
+        return orig(**arrays)
+    ens.set_forcings_batched = tap
+    try:
+        cpl.step()
+    finally:
+        ens.set_forcings_batched = orig
+    sync()
+    pairs = (("U", "f_u"), ("V", "f_v"), ("THL", "f_thl"), ("QT", "f_qt"), ("SP", "f_ps"), ("QL", "f_ql"), ("QLp", "ql_ref"))
+    with eng.on_stream():
+        r1 = eng.forward(b.gcm, b.zf, snap, lf, dt, zh=b.zh, want_profiles=False, want_heights=False)
+        for key, name in pairs:
+            if key not in received or not _bits_equal(received[key], host(r1[name])):
+                bad.append("k1 %s: what the LES ensemble received differs from the synchronous recompute" % name)
+        checked.append("k1: 7 forcing arrays x %d columns received == recompute" % n)
+    g_h = {v: numpy.ascontiguousarray(buf.gcm_in.hn[v][:n][rows]) for v in spcpl.gcm_vars}
+    ref_f = orc.forward_batched(g_h, {k: numpy.ascontiguousarray(v[rows]) for k, v in snap_h.items()}, zf_h, zh_h, lf, dt)
+    for key, name in pairs:
+        if key not in received:
+            continue
+        if name == "f_thl":
+            err = float(numpy.abs(received[key][rows] - ref_f[name]).max())
+            bound = 8 * 2.220446049250313e-16 * float(numpy.abs(ref_f["thl"]).max()) * abs(lf) / dt
+            if not err <= bound:
+                bad.append("k1 f_thl: %.3e from the oracle on the row sample (bound %.3e)" % (err, bound))
+        elif not _bits_equal(received[key][rows], ref_f[name]):
+            bad.append("k1 %s: differs from the oracle on the row sample" % name)
+    checked.append("k1: oracle on %d sample rows" % len(rows))
+    return (not bad), {"leg": label, "columns": n, "transport": "per-array copies on copy streams" if buf.piecewise else "one copy per buffer",
+                       "arena": type(buf.gcm_in).__name__, "checked": checked, "failures": bad}
 
 
 def dropin_rate(eng, n_les=1024, steps=30, warmup=5, per_les_steps=5):
@@ -182,8 +344,12 @@ def dropin_rate(eng, n_les=1024, steps=30, warmup=5, per_les_steps=5):
     from sp_coupler_amd import models, spcpl, transfer
     from sp_coupler_amd.driver import Coupler
     spcpl.set_engine(None)                   # the engine spcpl.get_engine() picks by itself: what a drop-in user gets
-    out = {"n_cols": n_les, "levels": "91<->160", "unit": "column-exchanges/s", "engine": type(spcpl.get_engine()).__name__,
-           "note": "wall time of Coupler.step minus time inside model methods; includes H2D/D2H of every step"}
+
+    def engine_keys():
+        e = spcpl.get_engine()
+        return {"engine": type(e).__name__, "devices": [str(x.device) for x in getattr(e, "engines", [e])]}
+    out = dict({"n_cols": n_les, "levels": "91<->160", "unit": "column-exchanges/s",
+                "note": "wall time of Coupler.step minus time inside model methods; includes H2D/D2H of every step"}, **engine_keys())
     gcm, ens = models.make_batched_models(n_les, nG=91, nL=160, seed=3)
     cpl = Coupler(gcm, ens)
     import gc
@@ -204,6 +370,7 @@ def dropin_rate(eng, n_les=1024, steps=30, warmup=5, per_les_steps=5):
     out["batched_protocol"] = {"value": n_les / (ms_c * 1e-3), "steps": steps, "passes": 3,
                                "ms_per_step_coupler": ms_c, "ms_per_step_models": ms_m,
                                "ms_per_step_coupler_all_passes": [p_[0] for p_ in passes]}
+    ok_small, det_small = dropin_verify(cpl, gcm, ens, "batched_protocol (%d columns)" % n_les)
     # the same steps again with HIP events around every copy / launch (the events cost a little host time themselves)
     transfer.trace = tr = transfer.StepTrace()
     models.model_seconds = 0.0
@@ -273,12 +440,16 @@ def dropin_rate(eng, n_les=1024, steps=30, warmup=5, per_les_steps=5):
         cpl4.step()
     torch.cuda.synchronize()
     w4 = time.perf_counter() - t0
-    big = {"value": 35718 * 5 / (w4 - models.model_seconds), "ms_per_step_coupler": (w4 - models.model_seconds) / 5 * 1e3,
-           "ms_per_step_models": models.model_seconds / 5 * 1e3, "steps": 5,
+    m4 = models.model_seconds
+    ok_big, det_big = dropin_verify(cpl4, gcm4, ens4, "batched_protocol_35718_columns")
+    big = {"value": 35718 * 5 / (w4 - m4), "ms_per_step_coupler": (w4 - m4) / 5 * 1e3,
+           "ms_per_step_models": m4 / 5 * 1e3, "steps": 5, **engine_keys(),
            "note": "1.1 GB over PCIe per step, array by array on the transfer buffers' copy streams while the model objects fetch / "
                    "take the next variable: most of it is hidden behind the model calls (whose time is subtracted)"}
     del cpl4, gcm4, ens4
     out["batched_protocol_35718_columns"] = big
+    out["verified"] = bool(ok_small and ok_big)
+    out["verified_detail"] = [det_small, det_big]
     spcpl.set_engine(None)
     return out
 
@@ -329,8 +500,20 @@ def in_process_all_gpus(ids, factor, dt, args):
         step()
     multi.synchronize()
     el = time.perf_counter() - t0
+    # every device's block proves itself (sample_check: rows incl. the block's first and last, inputs read back from THAT
+    # device, plain-C oracle): the outputs left in HBM by the timed launches
+    checks = []
+    for d, (pf_, pb_) in enumerate(zip(fp.plans, bp.plans)):
+        if pf_ is None:
+            continue
+        try:
+            ok_d, det_d = sample_check(pf_.outputs, pb_.outputs, parts_g[d], parts_p[d], zfs[d], zhs[d], factor, dt)
+        except Exception as e:
+            ok_d, det_d = False, {"failures": ["sample_check raised %r" % (e,)]}
+        checks.append(dict(det_d, device="cuda:%d" % ids[d], rows=[int(b[d]), int(b[d + 1])], verified=bool(ok_d)))
     return {"workload": "config 4: %d synthetic SP columns, ONE process, row blocks on %d device(s) (multi.MultiDeviceEngine)" % (n, len(ids)),
-            "devices": ["cuda:%d" % i for i in ids], "distinct_devices": len(set(ids)), "partition": describe_partition(multi, n),
+            "devices": [device_identity(i) for i in ids], "distinct_devices": len(set(ids)), "partition": describe_partition(multi, n),
+            "verified": all(c["verified"] for c in checks), "verified_detail": checks,
             "value": n * steps / el, "unit": "column-exchanges/s", "steps": steps, "ms_per_step": el / steps * 1e3,
             "note": "no collective, no peer traffic; compare with scaling_anchor (one GPU) and the `--gpus N` lines (one rank per GPU)"}
 
@@ -349,6 +532,8 @@ class Workload:
             # as synthetic.make_batch_tiled on the host; tile 0 is the host batch `verified` checks)
             g, zf_d, zh_d, p, host = synthetic.make_batch_tiled_device(eng.device, n_cols, nG, nL, seed=seed + r,
                                                                         couple_surface=False, keys=need)
+            if r == 0:
+                self.inputs0 = (g, zf_d, zh_d, p)      # device tensors of batch 0 (sample_check reads its rows back)
             if r == 0 and keep_host:
                 self.host0 = host
             fp, bp = eng.plan_exchange(g, zf_d, zh_d, p, factor, factor, dt, cols_per_block=cols_per_block)
@@ -410,26 +595,54 @@ def self_launch(n_gpus, argv):
 
 
 def rehearse_cpu(args, rank, world):
-    """The N > 1 launch path without a GPU (CPU tests of the self-launch): gloo rendezvous, this rank's shard of the
-    workload, barrier, max-over-ranks of a per-rank time -- rank 0 prints the JSON line with `value: null`."""
+    """The N > 1 path without a GPU (CPU tests of the self-launch and of the self-proving line): gloo rendezvous, this
+    rank's shard of the workload, barrier, max-over-ranks of a per-rank time, and the per-rank check / identity / gather
+    machinery of the real run -- with the TEST engine (tests/fake_engine.py, NumPy oracle) standing in for the device, so
+    `sample_check` compares two independent CPU restatements.  Rank 0 prints the JSON line with `value: null`."""
+    import socket
     import torch
     import torch.distributed as dist
     from sp_coupler_amd import sharding, synthetic
     dist.init_process_group("gloo")
     cfg = args.config if args.config is not None else 4
     total_cols = args.cols or synthetic.CONFIGS[cfg][0]
+    nG, nL, seed = synthetic.CONFIGS[cfg][1:]
     lo, hi = sharding.shard_range(total_cols, rank, world)
     dist.barrier()
     tt = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     rows = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
     dist.all_gather(rows, torch.tensor([lo, hi]))
+    mine = {"rank": rank, "rows": [int(lo), int(hi)], "device": {"index": None, "name": "cpu (rehearsal)", "pci": socket.gethostname(),
+                                                                  "uuid": "pid %d" % os.getpid()},
+            "ms_per_step": 1.0 * (rank + 1), "verified": None, "check": None}
+    if hi - lo <= 1024:                     # small rehearsal shards: run the check for real
+        from tests.fake_engine import OracleEngine
+        g, zf, zh, p = synthetic.make_batch(hi - lo, nG, nL, seed + 1000 * rank, couple_surface=False)
+        t = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}                       # noqa: E731
+        gt, pt, zft, zht = t(g), t(p), torch.from_numpy(zf), torch.from_numpy(zh)
+        fp, bp = OracleEngine().plan_exchange(gt, zft, zht, pt, 1.0, 1.0, 900.0)
+        fp.launch(), bp.launch()
+        if os.environ.get("SPC_REHEARSAL_CORRUPT_RANK") == str(rank):                     # test hook: one rank's outputs are wrong
+            bp.outputs["f_T"][-1, 0] += 1.0
+        ok, det = sample_check(fp.outputs, bp.outputs, gt, pt, zft, zht, 1.0, 900.0, m=min(4096, max(3, args.check_rows)))
+        mine["verified"], mine["check"] = bool(ok), det
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, mine)
     if rank == 0:
+        ms = [r["ms_per_step"] for r in per_rank]
+        ver = [r["verified"] for r in per_rank]
         print(json.dumps({"metric": "SP column-exchanges/sec (GCM<->LES forcing+tendency)", "value": None, "rehearsal": "cpu",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "backend": "gloo",
+                          "ranks": dist.get_world_size(), "devices": [r["device"] for r in per_rank],
+                          "per_rank_ms": {"min": min(ms), "max": max(ms), "all": ms},
+                          "verified": (None if any(v is None for v in ver) else all(ver)),
+                          "per_rank": [{k: r[k] for k in ("rank", "rows", "verified", "check")} for r in per_rank],
                           "max_over_ranks_s": float(tt.item()), "shards": [[int(a), int(b)] for a, b in rows],
                           "config": {"workload": "config %d, %d columns over %d ranks" % (cfg, total_cols, world)}}))
     dist.destroy_process_group()
+    if rank == 0 and any(v is False for v in [r["verified"] for r in per_rank]):
+        sys.exit("bench.py --rehearse-cpu: a rank's outputs differ from the oracle")
 
 
 def main():
@@ -452,6 +665,7 @@ def main():
     ap.add_argument("--multi-devices", default=None,
                     help="N=1 extra `in_process_all_gpus`: config 4 through multi.MultiDeviceEngine on these device ids (default: every "
                          "visible GPU when there is more than one; '0,0' rehearses the path with two engines on one GPU; 'none' skips)")
+    ap.add_argument("--check-rows", type=int, default=4096, help="rows per rank / device in the N > 1 output check (sample_check)")
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="N>1 launch mechanics only (rendezvous, sharding, barrier, max-reduction over gloo; no GPU work): CPU tests")
     args = ap.parse_args()
@@ -556,7 +770,7 @@ def main():
     for i in range(args.steps):
         wl.step(i, sptr)
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = own_elapsed = time.perf_counter() - t0
     fence()
     if dist is not None:
         tt = torch.tensor([elapsed], device=eng.device if args.backend == "nccl" else "cpu", dtype=torch.float64)
@@ -666,6 +880,23 @@ def main():
         except Exception as e:                       # a reported extra, never fatal for the headline
             dropin = {"error": repr(e)}
 
+    # N > 1: every rank proves ITS outputs and says who it is (a line whose ranks all sat on one GPU, or whose shards were
+    # never checked, proves nothing): a sample of >= 4096 rows of the rank's block incl. its first and last row, inputs
+    # read back from the device, plain-C oracle on the host, compared with what the timed plans left in HBM
+    per_rank = None
+    if dist is not None:
+        g0, zf0, zh0, p0 = wl.inputs0
+        try:
+            ok_r, det_r = sample_check(wl.fplans[0].outputs, wl.bplans[0].outputs, g0, p0, zf0, zh0, factor, dt_gcm,
+                                       m=max(4096, args.check_rows))
+        except Exception as e:                          # a rank that cannot check reports that, it does not hang the others
+            ok_r, det_r = False, {"failures": ["sample_check raised %r" % (e,)]}
+        mine = {"rank": rank, "local_rank": local, "rows": [int(lo), int(hi)], "device": device_identity(local), "verified": bool(ok_r),
+                "check": det_r, "ms_per_step": own_elapsed / args.steps * 1e3, "k1_avg_launch_us": k1_us, "k3_avg_launch_us": k3_us,
+                "pid": os.getpid()}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -693,7 +924,20 @@ def main():
                         "value(N) by value(1)"),
         "bytes_per_exchange": ab["exchange"],
         "hbm_frac_whole_step": value / world * ab["exchange"] / 1e9 / HBM_PEAK_GBS,
+        "ranks": (dist.get_world_size() if dist is not None else 1),
+        "devices": ([r["device"] for r in per_rank] if per_rank else [device_identity(local)]),
     }
+    roof_rank = 0
+    if per_rank:
+        ms = [r["ms_per_step"] for r in per_rank]
+        out["per_rank_ms"] = {"min": min(ms), "max": max(ms), "all": ms}
+        out["distinct_devices"] = len({(r["device"]["pci"], r["device"]["uuid"]) for r in per_rank})
+        out["per_rank"] = [{k: r[k] for k in ("rank", "local_rank", "rows", "verified", "check", "k1_avg_launch_us", "k3_avg_launch_us", "pid")}
+                           for r in per_rank]
+        if all(r["k1_avg_launch_us"] is not None for r in per_rank):       # the roofline object is the SLOWEST rank's
+            roof_rank = max(range(world), key=lambda i: per_rank[i]["k1_avg_launch_us"])
+            k1_us, k3_us = per_rank[roof_rank]["k1_avg_launch_us"], per_rank[roof_rank]["k3_avg_launch_us"]
+            n_cols = per_rank[roof_rank]["rows"][1] - per_rank[roof_rank]["rows"][0]
     if k1_us is not None:
         traffic, tsrc = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -707,6 +951,7 @@ def main():
                 traffic = None
         ach = ab["k1_launch"] * n_cols / (k1_us * 1e-6) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "k_forward (K1, fused K2 index map), lean hot-path variant",
+                           "rank": roof_rank, "rank_choice": ("slowest K1 over the ranks" if per_rank else None),
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                            "traffic": traffic, "traffic_source": tsrc,
                            "frac_vs_pmc": (traffic / (k1_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None,
@@ -733,6 +978,12 @@ def main():
         out["dropin"] = dropin
         out["dropin_value"] = dropin.get("batched_protocol", {}).get("value")
     out["verified"] = None
+    if per_rank:
+        out["verified"] = all(r["verified"] for r in per_rank)
+        out["verified_detail"] = {"method": "every rank: sample_check (>= 4096 rows of its block incl. first and last row, inputs read "
+                                            "back from its device, plain-C oracle) after the timed region; AND over ranks",
+                                  "bit_exact": BIT_EXACT,
+                                  "failures": [("rank %d: " % r["rank"]) + f for r in per_rank for f in r["check"].get("failures", [])]}
     if args.cpu_seconds > 0 and world == 1:
         gcm, zf, zh, prof = wl.host0
         m = min(n_cols, 8192)             # bounded sample: the first m columns of batch 0, whole passes
@@ -756,6 +1007,9 @@ def main():
         dist.destroy_process_group()
     if out["verified"] is False:
         sys.exit("bench.py: outputs of the timed plans differ from the oracle: %s" % out["verified_detail"]["failures"])
+    if dropin is not None and dropin.get("verified") is False:
+        sys.exit("bench.py: the drop-in step delivered something else than the kernels compute: %s"
+                 % [f for d in dropin["verified_detail"] for f in d["failures"]])
 
 
 if __name__ == "__main__":

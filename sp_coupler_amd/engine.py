@@ -8,6 +8,7 @@ A *plan* (``ForwardPlan`` / ``BackwardPlan``) validates shapes once, freezes the
 and can then be launched repeatedly with one foreign call -- what the per-step driver and ``bench.py``
 use, so host overhead per step stays at two launches.
 """
+import contextlib
 import ctypes
 
 import torch
@@ -29,6 +30,24 @@ def _stream_ptr(stream, device=None):
     elif device is not None and stream.device != device:
         raise ValueError("stream is on %s, engine is on %s" % (stream.device, device))
     return ctypes.c_void_p(stream.cuda_stream)
+
+
+def _on_engine_stream(fn):
+    """run an Engine method with torch's current stream set to the stream its kernels launch on (``stream=`` argument, else
+    the engine's own): tensors it allocates belong to that stream, torch ops it issues (``.contiguous()``) are ordered
+    with the launch.  Nothing changes for an engine without a stream called without one."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *a, **kw):
+        st = kw.get("stream")
+        if st is None:
+            st = self.stream
+        if st is None:
+            return fn(self, *a, **kw)
+        with torch.cuda.stream(st):
+            return fn(self, *a, **kw)
+    return wrapper
 
 
 class _Checker:
@@ -147,9 +166,11 @@ class Engine:
     the reference (AMUSE quantities wrap float64 arrays), float32 for the tolerance sweep."""
 
     def __init__(self, device=None, dtype=torch.float64, stream=None):
-        """``stream``: a ``torch.cuda.Stream`` every plan of this engine launches on (None: the current stream at launch
-        time) -- several engines with their own streams on ONE device pipeline a large batch chunk by chunk
-        (multi.streamed_engine: the upload of chunk c + 1 overlaps the kernel and the download of chunk c)."""
+        """``stream``: a ``torch.cuda.Stream`` every plan and every K7 operator of this engine launches on (None: torch's
+        current stream of the device at launch time).  The engine's transfer buffers (``arena``) order their copies
+        against the same stream, and the tensors the engine allocates are allocated under it (``on_stream``), so an
+        engine with a stream of its own never depends on what stream is current in the caller.  Several such engines on
+        ONE device run the row blocks of a ``multi.MultiDeviceEngine`` batch concurrently."""
         self.stream = stream
         self.lib = _abi.load_library()          # raises SpcLibraryError if the HIP extension is missing
         if dtype not in _DTYPES:
@@ -180,17 +201,27 @@ class Engine:
     def empty(self, *shape, dtype=None):
         return torch.empty(*shape, device=self.device, dtype=dtype or self.dtype)
 
+    def on_stream(self):
+        """context in which torch's current stream IS this engine's stream (allocations, ``.to()`` / ``.cpu()`` copies and
+        torch ops issued inside are then ordered with the engine's launches); a no-op for an engine without a stream"""
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
+    def synchronize(self):
+        (self.stream if self.stream is not None else torch.cuda.current_stream(self.device)).synchronize()
+
     # -- transfer plumbing shared with multi.MultiDeviceEngine (which shards the same things over several devices) ----
     def arena(self, specs, rows=None):
         """named arrays in ONE pinned host buffer mirrored by ONE device buffer (transfer.Arena)"""
         from .transfer import Arena
-        return Arena(self.device, specs)
+        return Arena(self.device, specs, stream=self.stream)
 
     def to_devices(self, host_array, rows=None, n_cols=None):
         import numpy
-        return torch.from_numpy(numpy.ascontiguousarray(host_array)).to(self.device, self.dtype)
+        with self.on_stream():
+            return torch.from_numpy(numpy.ascontiguousarray(host_array)).to(self.device, self.dtype)
 
     # -- K1 (+K2) ---------------------------------------------------------------------------
+    @_on_engine_stream
     def plan_forward(self, gcm, zf, prof, factor, dt, zh=None, *, want_profiles=False, want_heights=True,
                      want_idx=None, couple_surface=False, cols_per_block=0, out=None):
         """Arithmetic of convert_profiles + set_les_forcings (splib/spcpl.py:171-246, 299-385) for all
@@ -272,10 +303,12 @@ class Engine:
         dims = _abi.Dims(n, nG, nL, pitchG or nG, pitchGh or nG + 1, pitchL or nL, shared, int(cols_per_block))
         return ForwardPlan(self, self._fwd, (ctypes.byref(dims), ctypes.byref(a)), ck.keep, res, dims, a)
 
+    @_on_engine_stream
     def forward(self, *args, stream=None, **kw):
         return self.plan_forward(*args, **kw).launch(stream)
 
     # -- K2 standalone ----------------------------------------------------------------------
+    @_on_engine_stream
     def plan_cloud_indices(self, zh, Zh, out=None, cols_per_block=0):
         """searchsorted(zh, Zh, 'right')[:-1][::-1] per column (splib/spcpl.py:26, 764); ``out``: int32 [n x nG]."""
         n, nGp1 = int(Zh.shape[0]), int(Zh.shape[1])
@@ -294,10 +327,12 @@ class Engine:
         dims = _abi.Dims(n, nG, nL, pitchI, pitchGh, pitchL, shared, int(cols_per_block))
         return CloudIndexPlan(self, self._idx, (ctypes.byref(dims), zh_ptr, Zh_ptr, idx.data_ptr()), ck.keep, {"idx": idx}, dims)
 
+    @_on_engine_stream
     def cloud_indices(self, zh, Zh, stream=None, cols_per_block=0):
         return self.plan_cloud_indices(zh, Zh, cols_per_block=cols_per_block).launch(stream)["idx"]
 
     # -- K3 ---------------------------------------------------------------------------------
+    @_on_engine_stream
     def plan_backward(self, gcm, zf, prof, factor, dt, Zf=None, *, want_start_index=True, conservative=False,
                       zh=None, Zh=None, cols_per_block=0, out=None):
         """Arithmetic of set_gcm_tendencies (splib/spcpl.py:388-555) for all columns. ``prof``: dict
@@ -352,6 +387,7 @@ class Engine:
         dims = _abi.Dims(n, nG, nL, pitchG or nG, pitchGh or nG + 1, pitchL or nL, shared, int(cols_per_block))
         return BackwardPlan(self, self._bwd, (ctypes.byref(dims), ctypes.byref(a)), ck.keep, res, dims, a)
 
+    @_on_engine_stream
     def backward(self, *args, stream=None, **kw):
         return self.plan_backward(*args, **kw).launch(stream)
 
@@ -368,6 +404,7 @@ class Engine:
         return fp, bp
 
     # -- K5 ---------------------------------------------------------------------------------
+    @_on_engine_stream
     def plan_diagnostics(self, gcm, zf=None, prof=None, out=None, cols_per_block=0):
         """spifs.nc diagnostics: Tv, THL, QT, Zf, Zh (splib/spcpl.py:176,197-198,214-215) and, when
         ``zf``/``prof`` are given, pf, t, ql_water on LES levels (splib/spcpl.py:402,408-409).  Output tensors are
@@ -406,10 +443,12 @@ class Engine:
         dims = _abi.Dims(n, nG, nL, pitchG or nG, pitchGh or nG + 1, pitchL or nL, shared, int(cols_per_block))
         return DiagnosticsPlan(self, self._diag, (ctypes.byref(dims), ctypes.byref(a)), ck.keep, res, dims, a)
 
+    @_on_engine_stream
     def diagnostics(self, gcm, zf=None, prof=None, stream=None, cols_per_block=0):
         return self.plan_diagnostics(gcm, zf, prof, cols_per_block=cols_per_block).launch(stream)
 
     # -- variability nudge (qt_forcing == 'variance') ------------------------------------------------
+    @_on_engine_stream
     def variability_nudge(self, qt, qsat, R, ql_av, qt_av, ql_ref, presf=None, thl=None, ql=None, constantT=False,
                           stream=None):
         """spcpl.variability_nudge (splib/spcpl.py:613-744) for all columns: ``qt`` [n x itot x jtot x k] is updated
@@ -451,7 +490,7 @@ class Engine:
             self._vn_work = torch.empty(need, dtype=torch.uint8, device=self.device)
         a.work, a.work_bytes = self._vn_work.data_ptr(), self._vn_work.numel()
         with torch.cuda.device(self.device):
-            rc = self.lib.spc_variability_nudge_f64(ctypes.byref(a), _stream_ptr(stream, self.device))
+            rc = self.lib.spc_variability_nudge_f64(ctypes.byref(a), _stream_ptr(stream if stream is not None else self.stream, self.device))
         _abi.check(self.lib, rc)
         return res
 
@@ -481,6 +520,7 @@ class Engine:
             rc = fn(*args, _stream_ptr(stream if stream is not None else self.stream, self.device))
         _abi.check(self.lib, rc)
 
+    @_on_engine_stream
     def exner(self, p, inverse=False, stream=None):
         """sputils.exner / iexner (splib/sputils.py:28-34), elementwise on a device tensor of any shape"""
         if p.device != self.device or p.dtype != self.dtype:
@@ -491,6 +531,7 @@ class Engine:
                    stream=stream)
         return out
 
+    @_on_engine_stream
     def interp(self, x, xp, fp, stream=None):
         """sputils.interp == numpy.interp (splib/sputils.py:82-86) for every row: fp [n_rows x n_xp] (or [n_xp]), xp the
         same shape or one shared [n_xp], x [n_rows x n_x] or one shared [n_x].  Returns [n_rows x n_x] ([n_x] when every
@@ -508,6 +549,7 @@ class Engine:
         self._call(getattr(self.lib, "spc_interp_" + _DTYPES[self.dtype]), ctypes.byref(a), stream=stream)
         return out[0] if one else out
 
+    @_on_engine_stream
     def searchsorted(self, a, v, side="left", stream=None):
         """sputils.searchsorted == numpy.searchsorted (splib/sputils.py:88-91) per row; int64 indices"""
         if side not in ("left", "right"):
@@ -521,6 +563,7 @@ class Engine:
         self._call(getattr(self.lib, "spc_searchsorted_" + _DTYPES[self.dtype]), ctypes.byref(args), stream=stream)
         return out[0] if one else out
 
+    @_on_engine_stream
     def interp_c(self, Zh, zh, q, rho=None, mode="interp_c", stream=None):
         """sputils.interp_c / interp_rho / integral (splib/sputils.py:94-197) per row: Zh [n_rows x (nG+1)] layer bounds, zh
         [nL] (shared) or [n_rows x nL] grid points, q (and rho) [n_rows x nL'] with nL' >= nL - 1 cell values.
@@ -551,6 +594,7 @@ class Engine:
         self._call(getattr(self.lib, "spc_interp_c_" + _DTYPES[self.dtype]), ctypes.byref(a), stream=stream)
         return out[0] if one else out
 
+    @_on_engine_stream
     def rms(self, a, stream=None):
         """sputils.rms (splib/sputils.py:23-24) of every row of a [n_rows x n] tensor (of the one row of a 1-D tensor)"""
         one = a.dim() == 1
@@ -561,6 +605,7 @@ class Engine:
         return out[0] if one else out
 
     # -- surface fluxes of columns without an LES -------------------------------------------------
+    @_on_engine_stream
     def plan_surface_fluxes(self, Ph_s, T_s, QLflux, QIflux, SHflux, TSflux, out=None):
         """(wthl, wqt) of spcpl.convert_surface_fluxes (splib/spcpl.py:153-161) for [n] scalars."""
         n = int(Ph_s.shape[0])
@@ -574,6 +619,7 @@ class Engine:
         fn = getattr(self.lib, "spc_surface_fluxes_" + _DTYPES[self.dtype])
         return SurfacePlan(self, fn, [n] + ptrs + optr, ck.keep, {"wthl": wthl, "wqt": wqt})
 
+    @_on_engine_stream
     def surface_fluxes(self, Ph_s, T_s, QLflux, QIflux, SHflux, TSflux, stream=None):
         r = self.plan_surface_fluxes(Ph_s, T_s, QLflux, QIflux, SHflux, TSflux).launch(stream)
         return r["wthl"], r["wqt"]

@@ -6,8 +6,9 @@ gives device d rows ``shard_bounds(n, k)[d:d+2]`` of every ``[n x n_lev]`` array
 ``sharding.py`` uses for one-rank-per-GPU runs; the shared LES grid is replicated), and issues each device's copies
 and launches on that device's own stream, one device after the other -- everything is asynchronous, so the devices
 work concurrently.  Columns are independent (``splib.py:317,330``): no collective, no peer traffic on the hot path.
-``spcpl.get_engine()`` returns one when more than one GPU is visible, so ``driver.Coupler.step`` and the
-reference-named ``spcpl`` calls use every GPU without any change on the caller's side.
+``spcpl.get_engine()`` returns one when ``SPC_DEVICES`` asks for it (``all`` or a list of ids; opt-in since round 4: the
+path has only ever run on engines sharing one card), so ``driver.Coupler.step`` and the reference-named ``spcpl`` calls
+use every GPU without any change on the caller's side.
 
 Plans mirror ``engine._Plan`` (``set_scalars`` / ``launch`` / ``outputs``): a ``MultiPlan`` holds the per-device
 plans, its ``outputs`` are ``transfer.Sharded`` arrays.  Small batches stay on fewer devices (``MIN_COLS_PER_DEVICE``):
@@ -60,8 +61,8 @@ class MultiDeviceEngine:
     def __init__(self, engines=None, dtype=torch.float64, min_cols_per_device=MIN_COLS_PER_DEVICE):
         if engines is None:
             from .engine import Engine
-            ids = [int(x) for x in os.environ["SPC_DEVICES"].split(",")] if os.environ.get("SPC_DEVICES") else \
-                list(range(torch.cuda.device_count()))
+            want = os.environ.get("SPC_DEVICES", "").strip()
+            ids = [int(x) for x in want.split(",")] if want and want != "all" else list(range(torch.cuda.device_count()))
             engines = [Engine("cuda:%d" % i, dtype=dtype) for i in ids]
         if not engines:
             raise RuntimeError("MultiDeviceEngine needs at least one engine")
@@ -188,6 +189,10 @@ class MultiDeviceEngine:
 
     def variability_nudge(self, *a, **kw):
         return self.primary.variability_nudge(*a, **kw)
+
+    def on_stream(self):
+        """the slow paths run on the primary engine: its stream context (Engine.on_stream)"""
+        return self.primary.on_stream()
 
     def synchronize(self):
         for e in self.engines:

@@ -57,20 +57,29 @@ writer_rows = {}   # GCM grid index -> column index in the writer's file, for th
 
 
 def get_engine():
-    """the engine of this process: every visible GPU behind ONE master process (multi.MultiDeviceEngine: the column
-    batch split into row blocks, one per GPU -- the reference's master is one process holding all LES objects,
-    splib/splib.py:146-154) when there are several; a plain ``Engine`` with one GPU, inside a one-rank-per-GPU job
-    (WORLD_SIZE > 1: that rank's LOCAL_RANK device) or with SPC_SINGLE_GPU=1."""
+    """the engine of this process.  Default: ONE plain ``Engine`` -- inside a one-rank-per-GPU job (WORLD_SIZE > 1) on
+    that rank's LOCAL_RANK device, else on the current device.  Every visible GPU behind this ONE master process
+    (multi.MultiDeviceEngine: the column batch split into row blocks, one per GPU -- the reference's master is one
+    process holding all LES objects, splib/splib.py:146-154) is OPT-IN: ``SPC_DEVICES=all`` or ``SPC_DEVICES=0,1,...``
+    in the environment, or ``set_engine(MultiDeviceEngine(...))``; the choice and the row partition are logged.  (It
+    was the default in round 3; it has only ever run on two engines sharing one card, so a multi-GPU node no longer
+    gets it silently.)"""
     global _engine
     if _engine is None:
         import os
+        want = os.environ.get("SPC_DEVICES", "").strip()
         if int(os.environ.get("WORLD_SIZE", "1")) > 1:
             _engine = Engine("cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")))
-        elif torch.cuda.device_count() > 1 and os.environ.get("SPC_SINGLE_GPU") != "1":
+        elif want and os.environ.get("SPC_SINGLE_GPU") != "1":
             from .multi import MultiDeviceEngine
             _engine = MultiDeviceEngine()
+            log.warning("sp_coupler_amd: SPC_DEVICES=%s -> MultiDeviceEngine on %s (row blocks of >= %d columns per device)",
+                        want, ", ".join(str(e.device) for e in _engine.engines), _engine.min_cols_per_device)
         else:
             _engine = Engine()
+            if torch.cuda.device_count() > 1:
+                log.info("sp_coupler_amd: %d GPUs visible, using %s only (SPC_DEVICES=all spreads the column batch over all of them)",
+                         torch.cuda.device_count(), _engine.device)
     return _engine
 
 
@@ -100,7 +109,8 @@ def _num(q):
 
 
 def _to_host(t):
-    """device tensor (or a transfer.Sharded array of a multi-device engine) -> NumPy array"""
+    """device tensor (or a transfer.Sharded array of a multi-device engine) -> NumPy array.  Callers on the slow paths run
+    under ``engine.on_stream()``, so the copy is ordered behind the engine's launches."""
     if isinstance(t, transfer.Sharded):
         t = t.gather()
     return t.cpu().numpy()
@@ -252,6 +262,7 @@ class ColumnBatch:
         self.cols = list(cols)
         self.cols_arr = numpy.asarray(self.cols)          # what the GCM getters are handed (an index array, not a list)
         self.gi_ref = self.ens.grid_indices if self.ens is not None else None
+        self.gi_copy = numpy.array(self.gi_ref) if self.ens is not None else None     # an ensemble may re-mask IN PLACE
         self.couple_surface = bool(couple_surface)
         n_total = len(cols)
         self.use_out = bool(getattr(gcm, "supports_out", False))
@@ -295,6 +306,7 @@ class ColumnBatch:
         arena = self.buf.gcm_in
         hn, cols, use_out = arena.hn, self.cols_arr, self.use_out
         for v in gcm_vars:                                                    # spcpl.py:62-67
+            arena.writable(v)                       # (last step's upload of it has long left the pinned buffer: free)
             if v == gcm_vars[0] and first is not None:
                 numpy.copyto(hn[v], first)
             elif use_out:
@@ -304,6 +316,7 @@ class ColumnBatch:
             arena.push(v, "h2d_gcm")                # on the wire while the next variable is being fetched from the GCM
         if self.couple_surface:
             for v in surf_vars:                                               # spcpl.py:69-75
+                arena.writable(v)
                 if use_out:
                     gcm.get_surface_field(v, cols, out=hn[v])
                 else:
@@ -383,6 +396,7 @@ class ColumnBatch:
         rows = [source(les) for les in self.les_models]
         for k in keys:
             dst = hn[k]
+            self.buf.les_in.writable(k)
             try:                                    # fast: all columns hold the same kind of value
                 vals = [r[k] for r in rows]
                 v0 = vals[0]
@@ -410,6 +424,7 @@ class ColumnBatch:
         hn = self.buf.les_in.hn
         for k in keys:
             if arrays is not None and arrays[k] is not hn[k]:
+                self.buf.les_in.writable(k)
                 numpy.copyto(hn[k], _num(arrays[k]))
             self.buf.les_in.push(k, "h2d_les")
         return {k: self.buf.les_in.d[k] for k in keys}
@@ -447,8 +462,8 @@ def gather_gcm_data(gcm, les_models, couple_surface, output_column_indices=None,
     prev = _current
     if (ens is not None and prev is not None and prev.ens is ens and prev.gi_ref is ens.grid_indices and prev.engine is eng
             and prev.extra_cols == extra_cols and prev.couple_surface == bool(couple_surface)
-            and _buffers.get(prev.buf.key) is prev.buf):
-        cols = prev.cols                     # the same ensemble object as last step: nothing to rebuild or compare
+            and _buffers.get(prev.buf.key) is prev.buf and numpy.array_equal(prev.gi_copy, ens.grid_indices)):
+        cols = prev.cols                     # the same ensemble object with the same columns as last step: nothing to rebuild
     else:
         cols = ([int(g) for g in ens.grid_indices] if ens is not None else [les.grid_index for les in les_models]) + extra_cols
     if not any(cols):                                                        # quirk kept: spcpl.py:63,71
@@ -660,11 +675,13 @@ def convert_profiles(les, write=True):
     if batch.conv is None:
         eng = batch.engine
         nL = batch.zf.shape[-1]
-        z = torch.zeros(batch.n, nL, device=eng.device, dtype=eng.dtype)
-        dummy = {"U": z, "V": z, "THL": z, "QT": z, "QL": z, "PS": torch.zeros(batch.n, device=eng.device, dtype=eng.dtype)}
+        with eng.on_stream():
+            z = torch.zeros(batch.n, nL, device=eng.device, dtype=eng.dtype)
+            dummy = {"U": z, "V": z, "THL": z, "QT": z, "QL": z, "PS": torch.zeros(batch.n, device=eng.device, dtype=eng.dtype)}
         _inputs_ready(batch)
-        res = eng.forward(batch.gcm, batch.zf, dummy, 0.0, 1.0, want_profiles=True, want_heights=True)
-        batch.conv = {k: _to_host(res[k]) for k in ("u", "v", "thl", "qt", "ps", "ql_ref", "Zf", "Zh")}
+        with eng.on_stream():
+            res = eng.forward(batch.gcm, batch.zf, dummy, 0.0, 1.0, want_profiles=True, want_heights=True)
+            batch.conv = {k: _to_host(res[k]) for k in ("u", "v", "thl", "qt", "ps", "ql_ref", "Zf", "Zh")}
     c = batch.conv
     _attach_heights(batch, les, i)                                           # spcpl.py:200-201
     return (_wrap("u", c["u"][i]), _wrap("v", c["v"][i]), _wrap("thl", c["thl"][i]), _wrap("qt", c["qt"][i]),
@@ -748,9 +765,12 @@ def _ensemble_forcings(ens, firststep, profiles, dt_gcm, factor, couple_surface,
     if firststep:                                                            # spcpl.py:302-308, 321
         if b.piecewise:
             for k in _FWD_KEYS:                 # variable by variable: each is on the wire while the next is fetched
+                b.les_in.writable(k)
                 ens.get_profiles_batched((k,), {k: hn[k]})
                 b.les_in.push(k, "h2d_les")
         else:
+            for k in _FWD_KEYS:
+                b.les_in.writable(k)
             ens.get_profiles_batched(_FWD_KEYS, {k: hn[k] for k in _FWD_KEYS})
             for k in _FWD_KEYS:
                 b.les_in.push(k, "h2d_les")
@@ -792,9 +812,10 @@ def convert_surface_fluxes(les):
         Ph, T = numpy.atleast_2d(_num(les["Ph"])), numpy.atleast_2d(_num(les["T"]))   # KeyError if missing, spcpl.py:146
         one = numpy.ndim(_num(les["T"])) == 1
         dev = lambda a: torch.from_numpy(numpy.ascontiguousarray(numpy.atleast_1d(_num(a)))).to(eng.device, eng.dtype)  # noqa: E731
-        wthl, wqt = eng.surface_fluxes(dev(Ph[:, -1]), dev(T[:, -1]), dev(les["QLflux"]), dev(les["QIflux"]),
-                                       dev(les["SHflux"]), dev(les["TSflux"]))
-        wthl, wqt = wthl.cpu().numpy(), wqt.cpu().numpy()
+        with eng.on_stream():
+            wthl, wqt = eng.surface_fluxes(dev(Ph[:, -1]), dev(T[:, -1]), dev(les["QLflux"]), dev(les["QIflux"]),
+                                           dev(les["SHflux"]), dev(les["TSflux"]))
+            wthl, wqt = wthl.cpu().numpy(), wqt.cpu().numpy()
         sel = (lambda a: a[0]) if one else (lambda a: a)
         return les.get("Z0M"), les.get("Z0H"), _wrap("wthl", sel(wthl)), _wrap("wqt", sel(wqt))
     batch = _batch_of(les)
@@ -899,12 +920,16 @@ def get_les_profiles_batched(les_models, asynchronous=False, diagnostics=False):
     keys = _LES_IN_LEVELS + ("PS", "Rain") + (_LES_DIAG_LEVELS if diagnostics else ())
     if b.piecewise:
         for k in keys:                          # variable by variable: each is on the wire while the next is fetched
+            b.les_in.writable(k)
             ens.get_profiles_batched((k,), {k: hn[k]})
             b.les_in.push(k, "h2d_les")
     else:
+        for k in keys:
+            b.les_in.writable(k)
         ens.get_profiles_batched(keys, {k: hn[k] for k in keys})
         for k in keys:
             b.les_in.push(k, "h2d_les")
+    b.les_in.writable("A")
     ens.get_cloudfraction_batched(_index_map(batch), hn["A"])                 # spcpl.py:761-765
     b.les_in.push("A", "h2d_les")
     batch.profile_generation += 1
@@ -1002,13 +1027,15 @@ def _write_backward(batch, prof):
     the slab means incl. THL, presf, Rhof, Rhobf, QR."""
     b, n = batch.bwd, batch.n
     _inputs_ready(batch)
-    d = batch.engine.diagnostics(batch.gcm, batch.zf, prof)                                  # K5: t, ql_water
     h = _to_host
-    writer.write(u=h(prof["U"]), v=h(prof["V"]), presf=h(prof["presf"]), rhof=h(prof["Rhof"]),
-                 rhobf=h(prof["Rhobf"]), qt=h(prof["QT"]), ql=h(prof["QL"]), ql_ice=h(prof["QL_ice"]),
-                 ql_water=h(d["ql_water"]), thl=h(prof["THL"]), t=h(d["t"]), t_=h(prof["T"]), qr=h(prof["QR"]),
-                 f_U=b["f_U"], f_V=b["f_V"], f_T=b["f_T"], f_SH=b["f_SH"], f_QL=b["f_QL"], f_QI=b["f_QI"], f_A=b["f_A"],
-                 A=batch.gcm_host["A"][:n], A_d=h(prof["A"])[:, ::-1])                       # spcpl.py:404,550-551
+    with batch.engine.on_stream():
+        d = batch.engine.diagnostics(batch.gcm, batch.zf, prof)                              # K5: t, ql_water
+        dev = dict(u=h(prof["U"]), v=h(prof["V"]), presf=h(prof["presf"]), rhof=h(prof["Rhof"]),
+                   rhobf=h(prof["Rhobf"]), qt=h(prof["QT"]), ql=h(prof["QL"]), ql_ice=h(prof["QL_ice"]),
+                   ql_water=h(d["ql_water"]), thl=h(prof["THL"]), t=h(d["t"]), t_=h(prof["T"]), qr=h(prof["QR"]),
+                   A_d=h(prof["A"])[:, ::-1])                                                # spcpl.py:404
+    writer.write(f_U=b["f_U"], f_V=b["f_V"], f_T=b["f_T"], f_SH=b["f_SH"], f_QL=b["f_QL"], f_QI=b["f_QI"], f_A=b["f_A"],
+                 A=batch.gcm_host["A"][:n], **dev)                                           # spcpl.py:550-551
 
 
 def set_gcm_tendencies_batched(gcm, les_models, profiles, dt_gcm, factor=1, write=True, conservative=False):
@@ -1087,6 +1114,8 @@ def write_les_profiles_batched(les_models):
     if _is_ensemble(les_models):
         batch = _batch_of(les_models)
         hn = batch.buf.les_in.hn
+        for k in keys:
+            batch.buf.les_in.writable(k)
         les_models.get_profiles_batched(keys, {k: hn[k] for k in keys})
         prof = batch.upload_profiles(keys)
     else:
@@ -1096,11 +1125,12 @@ def write_les_profiles_batched(les_models):
                          "QL_ice": m.get_profile_QL_ice(), "QR": m.get_profile_QR(), "T": m.get_profile_T()}
         prof = batch.stack_profiles(keys, src)
     _inputs_ready(batch)
-    d = batch.engine.diagnostics(batch.gcm, batch.zf, prof)                                  # K5: t, ql_water
     h = _to_host
-    out = dict(u=h(prof["U"]), v=h(prof["V"]), presf=h(prof["presf"]), qt=h(prof["QT"]), ql=h(prof["QL"]),
-               ql_ice=h(prof["QL_ice"]), ql_water=h(d["ql_water"]), thl=h(prof["THL"]), t=h(d["t"]), t_=h(prof["T"]),
-               qr=h(prof["QR"]))
+    with batch.engine.on_stream():
+        d = batch.engine.diagnostics(batch.gcm, batch.zf, prof)                              # K5: t, ql_water
+        out = dict(u=h(prof["U"]), v=h(prof["V"]), presf=h(prof["presf"]), qt=h(prof["QT"]), ql=h(prof["QL"]),
+                   ql_ice=h(prof["QL_ice"]), ql_water=h(d["ql_water"]), thl=h(prof["THL"]), t=h(d["t"]), t_=h(prof["T"]),
+                   qr=h(prof["QR"]))
     if writer is not None:
         writer.write(**out)
     return out
@@ -1133,11 +1163,12 @@ def _vnudge_launch(F, Rs, constantT):
     eng = get_engine()
     dev, dt = eng.device, eng.dtype
     up = lambda a: torch.from_numpy(numpy.ascontiguousarray(a)).to(dev, dt)      # noqa: E731
-    T = {k: up(v) for k, v in F.items() if v is not None}
-    res = eng.variability_nudge(T["qt"], T["qsat"], up(Rs), T["ql_av"], T["qt_av"], T["ql_ref"], presf=T["presf"],
-                                thl=T.get("thl"), ql=T.get("ql"), constantT=constantT)
-    host = {k: v.cpu().numpy() for k, v in res.items()}
-    return host, T["qt"].cpu().numpy(), (T["thl"].cpu().numpy() if constantT else None)
+    with eng.on_stream():
+        T = {k: up(v) for k, v in F.items() if v is not None}
+        res = eng.variability_nudge(T["qt"], T["qsat"], up(Rs), T["ql_av"], T["qt_av"], T["ql_ref"], presf=T["presf"],
+                                    thl=T.get("thl"), ql=T.get("ql"), constantT=constantT)
+        host = {k: v.cpu().numpy() for k, v in res.items()}
+        return host, T["qt"].cpu().numpy(), (T["thl"].cpu().numpy() if constantT else None)
 
 
 def _vnudge_finish(host, rows, dtv, write):
@@ -1241,11 +1272,12 @@ def output_column_conversion(profile):
     eng = get_engine()
     one = numpy.asarray(_num(profile["T"])).ndim == 1
     g = {}
-    for src, dst in (("T", "T"), ("SH", "SH"), ("QL", "QL"), ("QI", "QI"), ("Pf", "Pfull"), ("Zgfull", "Zgfull"),
-                     ("Zghalf", "Zghalf")):
-        a = numpy.atleast_2d(_num(profile[src]))
-        g[dst] = torch.from_numpy(numpy.ascontiguousarray(a)).to(eng.device, eng.dtype)
-    d = {k: v.cpu().numpy() for k, v in eng.diagnostics(g).items()}
+    with eng.on_stream():
+        for src, dst in (("T", "T"), ("SH", "SH"), ("QL", "QL"), ("QI", "QI"), ("Pf", "Pfull"), ("Zgfull", "Zgfull"),
+                         ("Zghalf", "Zghalf")):
+            a = numpy.atleast_2d(_num(profile[src]))
+            g[dst] = torch.from_numpy(numpy.ascontiguousarray(a)).to(eng.device, eng.dtype)
+        d = {k: v.cpu().numpy() for k, v in eng.diagnostics(g).items()}
     sel = (lambda a: a[0]) if one else (lambda a: a)
     Ph = numpy.atleast_2d(_num(profile["Ph"]))
     profile["Tv"] = sel(d["Tv"])

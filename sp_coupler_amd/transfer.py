@@ -10,13 +10,19 @@ class Arena:
     """Named arrays packed into ONE pinned host buffer and ONE device buffer, so that a whole group of inputs
     (or results) crosses PCIe in a single copy.  ``h[name]`` / ``hn[name]`` are the host views (torch / NumPy),
     ``d[name]`` the device views; every array starts 256-B aligned (the 16-B accesses of the compile-time-geometry
-    kernels need aligned bases).  With a CPU "device" (the test-only oracle engine) host and device are one buffer."""
+    kernels need aligned bases).  With a CPU "device" (the test-only oracle engine) host and device are one buffer.
+
+    ``stream``: the COMPUTE stream the kernels reading / writing this buffer are launched on (an engine's own stream,
+    ``Engine(stream=...)``); None = torch's current stream of the device at the time of each call.  Every ordering
+    below (single copies, fences of the copy stream, events) is taken against that stream, never against whatever
+    stream happens to be current when an engine launches elsewhere."""
 
     ALIGN = 256
     PIECE_MIN = 4 << 20          # arrays smaller than this travel together in one copy, larger ones each on their own
 
-    def __init__(self, device, specs):
+    def __init__(self, device, specs, stream=None):
         self.device = torch.device(device)
+        self.stream = stream
         off, lay = 0, []
         for name, shape, dtype in specs:
             nbytes = int(numpy.prod(shape, dtype=numpy.int64)) * torch.empty((), dtype=dtype).element_size()
@@ -34,33 +40,63 @@ class Arena:
             self.begin[name], self.end[name] = o, o + nb
         self.done = None        # event of the last download (created on first use)
         self.side, self.pushed, self.landed, self.pending, self.deferred, self.deferred_what = None, False, {}, {}, None, "h2d"
+        self.sent, self.sent_ev = {}, {}     # name -> event recorded behind the last upload of that array (writable())
+
+    def _cur(self):
+        """the compute stream every copy of this buffer is ordered against"""
+        return self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
+
+    def _copy(self, dst, src, what, nbytes, stream):
+        """one async copy issued on ``stream`` (torch issues copies on ITS current stream: make ``stream`` that)"""
+        with torch.cuda.stream(stream):
+            if trace is not None:
+                with trace.region(what, nbytes, self.device):
+                    dst.copy_(src, non_blocking=True)
+            else:
+                dst.copy_(src, non_blocking=True)
+
+    def _mark_sent(self, names, stream):
+        """one event behind the copy that carried ``names`` up: the host may refill them once it has fired"""
+        if not names:
+            return
+        ev = self.sent_ev.get(names[0])
+        if ev is None:
+            ev = self.sent_ev[names[0]] = torch.cuda.Event()
+        ev.record(stream)
+        for nm in names:
+            self.sent[nm] = ev
+
+    def writable(self, name):
+        """wait until the last upload of ``name`` has left the pinned host buffer (call before refilling it on the
+        host).  Free in the normal call order: a step waits for its results, hence for the kernel behind the uploads."""
+        ev = self.sent.pop(name, None)         # (an array collected for the copy at the next fence() is not on the wire)
+        if ev is not None:
+            ev.synchronize()
+
+    def _names_in(self, lo, hi):
+        return [nm for nm in self.begin if lo <= self.begin[nm] and self.end[nm] <= hi]
 
     def upload(self, upto=None, what="h2d"):
-        """host -> device (one async copy on the current stream; later kernels on that stream are ordered after it)"""
+        """host -> device (one async copy on the compute stream; later kernels on that stream are ordered after it)"""
         if self.dev is not self.host:
             n = self.nbytes if upto is None else self.end[upto]
-            if trace is not None:
-                with trace.region(what, n, self.device):
-                    self.dev[:n].copy_(self.host[:n], non_blocking=True)
-            else:
-                self.dev[:n].copy_(self.host[:n], non_blocking=True)
+            cur = self._cur()
+            self._copy(self.dev[:n], self.host[:n], what, n, cur)
+            self._mark_sent(self._names_in(0, n), cur)
 
     def download(self, upto=None, what="d2h", start=None):
         """device -> host of the arrays from ``start`` (default the first) up to and including ``upto`` (default the
-        last), then wait for THAT copy (an event of this arena, not a synchronisation of the whole stream)"""
+        last) on the compute stream, then wait for THAT copy (an event of this arena, not a synchronisation of the
+        whole stream)"""
         if self.dev is not self.host:
             n = self.nbytes if upto is None else self.end[upto]
             o = 0 if start is None else self.begin[start]
-            if trace is not None:
-                with trace.region(what, n - o, self.device):
-                    self.host[o:n].copy_(self.dev[o:n], non_blocking=True)
-            else:
-                self.host[o:n].copy_(self.dev[o:n], non_blocking=True)
+            cur = self._cur()
+            self._copy(self.host[o:n], self.dev[o:n], what, n - o, cur)
             if self.done is None:
                 self.done = torch.cuda.Event()
-            self.done.record(torch.cuda.current_stream(self.device))
+            self.done.record(cur)
             self.done.synchronize()
-
 
     # ---- piecewise transfers on a copy stream of the arena's own: overlapped with the host's model calls ----------------
     def _side(self):
@@ -80,73 +116,57 @@ class Arena:
             return
         side = self._side()
         if not self.pushed:      # first push since the last fence(): a kernel launched earlier on the compute stream may still
-            side.wait_stream(torch.cuda.current_stream(self.device))     # be reading this buffer (write-after-read)
-        with torch.cuda.stream(side):
-            if trace is not None:
-                with trace.region(what, n - o, self.device):
-                    self.dev[o:n].copy_(self.host[o:n], non_blocking=True)
-            else:
-                self.dev[o:n].copy_(self.host[o:n], non_blocking=True)
+            side.wait_stream(self._cur())                                # be reading this buffer (write-after-read)
+        self._copy(self.dev[o:n], self.host[o:n], what, n - o, side)
+        self._mark_sent([name], side)
         self.pushed = True
 
     def fence(self):
-        """the CURRENT stream waits for every ``push()`` issued so far (call before launching the kernel that reads them)"""
+        """the COMPUTE stream waits for every ``push()`` issued so far (call before launching the kernel that reads them)"""
         if self.dev is self.host:
             return
+        cur = self._cur()
         if self.deferred is not None:
             lo, hi = self.deferred
             self.deferred = None
-            if trace is not None:
-                with trace.region(self.deferred_what, hi - lo, self.device):
-                    self.dev[lo:hi].copy_(self.host[lo:hi], non_blocking=True)
-            else:
-                self.dev[lo:hi].copy_(self.host[lo:hi], non_blocking=True)
+            self._copy(self.dev[lo:hi], self.host[lo:hi], self.deferred_what, hi - lo, cur)
+            self._mark_sent(self._names_in(lo, hi), cur)
         if self.pushed:
-            torch.cuda.current_stream(self.device).wait_stream(self.side)
+            cur.wait_stream(self.side)
             self.pushed = False
 
     def settle(self):
-        """the CURRENT stream waits for pulls nobody has waited for yet (call before launching a kernel that overwrites
+        """the COMPUTE stream waits for pulls nobody has waited for yet (call before launching a kernel that overwrites
         this buffer on the device); free when every pull has been taken with ``ready()``, the normal case"""
         if self.dev is not self.host and self.pending:
-            torch.cuda.current_stream(self.device).wait_stream(self.side)
+            self._cur().wait_stream(self.side)
 
     def pull(self, names, what="d2h"):
         """device -> host of the named arrays, one after the other on the copy stream, each followed by an event of its
         own (``ready(name)`` waits for it): the host hands the first array to a model setter while the next ones are still
-        on the wire.  The copy stream first waits for what the current stream has been given so far (the producing kernel)."""
+        on the wire.  The copy stream first waits for what the compute stream has been given so far (the producing kernel)."""
         if self.dev is self.host:
             return
         side = self._side()
-        side.wait_stream(torch.cuda.current_stream(self.device))
+        side.wait_stream(self._cur())
         if all(self.end[nm] - self.begin[nm] < self.PIECE_MIN for nm in names):     # small: ONE copy of the covering range
             lo, hi = min(self.begin[nm] for nm in names), max(self.end[nm] for nm in names)
-            with torch.cuda.stream(side):
-                if trace is not None:
-                    with trace.region(what, hi - lo, self.device):
-                        self.host[lo:hi].copy_(self.dev[lo:hi], non_blocking=True)
-                else:
-                    self.host[lo:hi].copy_(self.dev[lo:hi], non_blocking=True)
-                ev = self.landed.get("*")
-                if ev is None:
-                    ev = self.landed["*"] = torch.cuda.Event()
-                ev.record(side)
+            self._copy(self.host[lo:hi], self.dev[lo:hi], what, hi - lo, side)
+            ev = self.landed.get("*")
+            if ev is None:
+                ev = self.landed["*"] = torch.cuda.Event()
+            ev.record(side)
             for nm in names:
                 self.pending[nm] = ev
             return
-        with torch.cuda.stream(side):
-            for name in names:
-                o, n = self.begin[name], self.end[name]
-                if trace is not None:
-                    with trace.region(what, n - o, self.device):
-                        self.host[o:n].copy_(self.dev[o:n], non_blocking=True)
-                else:
-                    self.host[o:n].copy_(self.dev[o:n], non_blocking=True)
-                ev = self.landed.get(name)
-                if ev is None:
-                    ev = self.landed[name] = torch.cuda.Event()
-                ev.record(side)
-                self.pending[name] = ev
+        for name in names:
+            o, n = self.begin[name], self.end[name]
+            self._copy(self.host[o:n], self.dev[o:n], what, n - o, side)
+            ev = self.landed.get(name)
+            if ev is None:
+                ev = self.landed[name] = torch.cuda.Event()
+            ev.record(side)
+            self.pending[name] = ev
 
     def ready(self, name=None):
         """wait until the pulled array ``name`` (default: every pulled array) is in host memory"""
@@ -282,6 +302,7 @@ class ShardedArena:
             self.order.append(name)
         self.done = [None] * len(self.devices)
         self.pending = {}
+        self.sent = {}          # name -> events behind the last upload of that array, one per device (writable())
 
     def _on(self, di):
         """context in which device di's copies are issued: its device, and its own stream if it has one"""
@@ -305,6 +326,16 @@ class ShardedArena:
             with self._on(di):
                 for name in names:
                     self.d[name].parts[di].copy_(self.h[name][lo:hi], non_blocking=True)
+                if dev.type == "cuda":
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(dev))
+                    for name in names:
+                        self.sent.setdefault(name, {})[di] = ev
+
+    def writable(self, name):
+        """wait until every device's last upload of ``name`` has left the pinned host buffer (Arena.writable)"""
+        for ev in self.sent.pop(name, {}).values():
+            ev.synchronize()
 
     def download(self, upto=None, what="d2h", start=None):
         names = self._names(upto, start)

@@ -56,9 +56,15 @@ class _OraclePlan:
 class OracleEngine:
     device, dtype = torch.device("cpu"), torch.float64
 
+    stream = None
+
     def arena(self, specs, rows=None):
         from sp_coupler_amd.transfer import Arena
         return Arena(self.device, specs)
+
+    def on_stream(self):
+        import contextlib
+        return contextlib.nullcontext()
 
     # -- the K7 operators (Engine.exner / interp / searchsorted / interp_c / rms) row by row through the oracle ----------
     @staticmethod

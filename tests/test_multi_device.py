@@ -111,6 +111,44 @@ def test_get_engine_inside_a_rank_per_gpu_job_takes_that_ranks_device(monkeypatc
         sp.set_engine(None)
 
 
+def test_all_gpus_behind_one_process_is_opt_in(monkeypatch):
+    """several visible GPUs no longer mean MultiDeviceEngine silently -- SPC_DEVICES asks for it"""
+    import torch
+    import sp_coupler_amd.multi as mm
+    import sp_coupler_amd.spcpl as sp
+    made = []
+    class FakeEngine:
+        device = "cuda:0"
+
+        def __init__(self, *a, **k):
+            made.append(("engine", a))
+    monkeypatch.setattr(sp, "Engine", FakeEngine)
+
+    class FakeMulti:
+        engines, min_cols_per_device = [], 2048
+
+        def __init__(self, *a, **k):
+            made.append(("multi", a))
+    monkeypatch.setattr(mm, "MultiDeviceEngine", FakeMulti)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("SPC_DEVICES", raising=False)
+    try:
+        sp.set_engine(None)
+        sp.get_engine()
+        assert made == [("engine", ())]
+        monkeypatch.setenv("SPC_DEVICES", "all")
+        sp.set_engine(None)
+        sp.get_engine()
+        assert made[-1][0] == "multi"
+        monkeypatch.setenv("SPC_SINGLE_GPU", "1")
+        sp.set_engine(None)
+        sp.get_engine()
+        assert made[-1][0] == "engine"
+    finally:
+        sp.set_engine(None)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("batched,cplsurf", [(True, False), (False, True)])
 def test_two_engines_on_one_gpu_through_the_hip_kernels(batched, cplsurf):

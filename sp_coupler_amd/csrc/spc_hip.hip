@@ -1213,7 +1213,10 @@ template <typename T> KBwd<T> cons_kernel(int geo, int pd)
 int cons_depth(int nL)
 {
     if (nL > 1024) return -1;
-    const int d = vn_pw_depth(nL);
+    // vn_pw_depth(n) = max over 129 .. n of the (triple-recursive) depth of n: a running maximum, filled ONCE (it was
+    // re-evaluated three times per K4 launch: tens of thousands of calls for a grid of ~1000 levels)
+    static const struct Tab { signed char d[1025]; Tab() { int m = 0; for (int n = 0; n <= 1024; ++n) { if (n >= 129) { const int dn = vn_pw_depth_of(n); if (dn > m) m = dn; } d[n] = (signed char)m; } } } tab;
+    const int d = nL < 0 ? 0 : tab.d[nL];
     return d < 1 ? 1 : (d <= 3 ? d : -1);
 }
 

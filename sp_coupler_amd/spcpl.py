@@ -1158,17 +1158,49 @@ def variability_nudge(les, DT, constantT=False, write=True):
     return variability_nudge_batched([les], DT, constantT, write)[0]
 
 
+VN_MAX_COLS = 32767          # columns per launch of spc_variability_nudge_f64 (include/spc.h: the grid's y extent)
+
+
+def _vnudge_chunk(eng, n, itot, jtot, ktot, constantT):
+    """columns per launch: the kernel's limit, and what fits the device -- fields (qt, qsat; thl, ql with constantT), the
+    transposed-plane workspace, R and the profiles, within 80 % of the memory that is free now.  The reference loops over any
+    number of LES (splib/spcpl.py:377-382); columns are independent, so chunks give the bits of one launch."""
+    chunk = min(int(VN_MAX_COLS), n)
+    dev = getattr(getattr(eng, "primary", eng), "device", None)
+    if dev is not None and dev.type == "cuda":
+        lib = getattr(eng, "lib", None)
+        per_col = (4 if constantT else 2) * itot * jtot * ktot * 8 + itot * jtot * 8 + 8 * ktot * 8
+        if lib is not None:
+            per_col += max(0, int(lib.spc_vnudge_workspace_bytes(1, itot, jtot, ktot)))
+        free, _ = torch.cuda.mem_get_info(dev)
+        chunk = max(1, min(chunk, int(0.8 * free) // max(per_col, 1)))
+    return chunk
+
+
 def _vnudge_launch(F, Rs, constantT):
-    """stacked host arrays -> ONE launch (K6) -> host results; ``F``: dict of [n x ...] arrays"""
+    """stacked host arrays -> as few launches of K6 as the kernel's column limit and the device memory allow -> host results;
+    ``F``: dict of [n x ...] arrays"""
     eng = get_engine()
     dev, dt = eng.device, eng.dtype
     up = lambda a: torch.from_numpy(numpy.ascontiguousarray(a)).to(dev, dt)      # noqa: E731
-    with eng.on_stream():
-        T = {k: up(v) for k, v in F.items() if v is not None}
-        res = eng.variability_nudge(T["qt"], T["qsat"], up(Rs), T["ql_av"], T["qt_av"], T["ql_ref"], presf=T["presf"],
-                                    thl=T.get("thl"), ql=T.get("ql"), constantT=constantT)
-        host = {k: v.cpu().numpy() for k, v in res.items()}
-        return host, T["qt"].cpu().numpy(), (T["thl"].cpu().numpy() if constantT else None)
+    n, itot, jtot, ktot = F["qt"].shape
+    chunk = _vnudge_chunk(eng, n, itot, jtot, ktot, constantT)
+    hosts, qts, thls = [], [], []
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        with eng.on_stream():
+            T = {k: up(v[lo:hi]) for k, v in F.items() if v is not None}
+            res = eng.variability_nudge(T["qt"], T["qsat"], up(Rs[lo:hi]), T["ql_av"], T["qt_av"], T["ql_ref"], presf=T["presf"],
+                                        thl=T.get("thl"), ql=T.get("ql"), constantT=constantT)
+            hosts.append({k: v.cpu().numpy() for k, v in res.items()})
+            qts.append(T["qt"].cpu().numpy())
+            if constantT:
+                thls.append(T["thl"].cpu().numpy())
+            del T, res
+    if len(hosts) == 1:
+        return hosts[0], qts[0], (thls[0] if constantT else None)
+    host = {k: numpy.concatenate([h[k] for h in hosts], axis=0) for k in hosts[0]}
+    return host, numpy.concatenate(qts, axis=0), (numpy.concatenate(thls, axis=0) if constantT else None)
 
 
 def _vnudge_finish(host, rows, dtv, write):

@@ -73,14 +73,15 @@ class SpifsWriter:
                 if var is None:
                     raise KeyError("Attempt to write profile to uninitialized variable %s" % name)   # spio.py:240
                 a = numpy.asarray(arr, dtype=numpy.float32)
-                if rows is None and a.ndim >= 1 and a.shape[0] < self.n:
-                    rows = numpy.arange(a.shape[0])      # the SP columns occupy the FIRST rows; extra output
+                sel = rows                               # per VARIABLE: arrays of one call may differ in their row count
+                if sel is None and a.ndim >= 1 and a.shape[0] < self.n:
+                    sel = numpy.arange(a.shape[0])       # the SP columns occupy the FIRST rows; extra output
                                                          # columns (spcpl.py:89-129) follow and keep their values
-                if rows is None:
+                if sel is None:
                     var[self.step] = a
                 else:
                     cur = numpy.array(var[self.step]) if var.shape[0] > self.step else numpy.zeros(var.shape[1:], "f4")
-                    cur[numpy.asarray(rows)] = a
+                    cur[numpy.asarray(sel)] = a
                     var[self.step] = cur
 
     def sync(self):

@@ -32,9 +32,25 @@ def _engine():
     return getattr(eng, "primary", eng)          # multi.MultiDeviceEngine: helpers run on its first device
 
 
-def _num(a):
-    """bare numbers of a (possibly unit-carrying) value"""
+def _num(a, unit=None):
+    """bare numbers of a (possibly unit-carrying) value; with ``unit`` (the unit of ANOTHER argument the reference
+    converts to: ``xp.value_in(x.unit)``, splib/sputils.py:86, 91) a quantity is converted, so that mixed units
+    (km against m) give the reference's numbers instead of silently wrong ones"""
+    if unit is not None and hasattr(a, "value_in"):
+        return a.value_in(unit)
     return a.number if hasattr(a, "number") else a
+
+
+def _unit(a):
+    return getattr(a, "unit", None) if hasattr(a, "number") else None
+
+
+def _with_unit(value, unit):
+    """``value | unit`` as the reference returns it (``... | fp.unit``, splib/sputils.py:86); plain numbers without one"""
+    if unit is None:
+        return value
+    new = getattr(unit, "new_quantity", None)       # amuse.units.core.unit: what `number | unit` calls
+    return new(value) if new is not None else (value | unit)
 
 
 class _Io:
@@ -44,8 +60,8 @@ class _Io:
         self.eng = _engine()
         self.on_device = False
 
-    def dev(self, a, dtype=None):
-        a = _num(a)
+    def dev(self, a, dtype=None, unit=None):
+        a = _num(a, unit)
         if isinstance(a, torch.Tensor):
             self.on_device = self.on_device or a.device.type == "cuda"
             return a.to(self.eng.device, dtype or self.eng.dtype)
@@ -75,27 +91,42 @@ def iexner(p):
     return io.back(io.eng.exner(pd, inverse=True), scalar=pd.dim() == 0)
 
 
-def rms(a):
-    """root mean square sqrt(mean(a ** 2)), splib/sputils.py:23-24; a 2-D argument gives the rms of every row"""
+def rms(a, axis=None):
+    """root mean square sqrt(mean(a ** 2)), splib/sputils.py:23-24: ONE number over the whole array whatever its shape, as
+    the reference (numpy.mean over every axis).  ``axis=-1`` (beyond the reference): the rms of every row of a 2-D array."""
     io = _Io()
+    unit = _unit(a)
     ad = io.dev(a)
-    if ad.dim() == 0:
-        ad = ad.reshape(1)
-    return io.back(io.eng.rms(ad), scalar=ad.dim() == 1)
+    if axis is None:
+        ad = ad.reshape(-1)                         # C order: numpy reduces a contiguous array as one flat run
+    elif axis not in (-1, 1) or ad.dim() != 2:
+        raise ValueError("rms: axis must be None (whole array, as the reference) or -1 on a 2-D array (per row)")
+    return _with_unit(io.back(io.eng.rms(ad), scalar=ad.dim() == 1), unit)
 
 
 def interp(x, xp, fp, **kwargs):
-    """numpy.interp(x, xp, fp) (splib/sputils.py:82-86) for one column (1-D arguments) or for every row of 2-D arguments
-    (x and xp may stay 1-D: shared by all rows).  numpy.interp's left / right / period are not supported."""
-    if kwargs:
-        raise NotImplementedError("sputils.interp on the GPU: numpy.interp's %s not supported" % sorted(kwargs))
+    """numpy.interp(x, xp, fp, **kwargs) (splib/sputils.py:82-86) for one column (1-D arguments) or for every row of 2-D
+    arguments (x and xp may stay 1-D: shared by all rows).  As the reference: ``xp`` is converted to ``x``'s unit, the
+    result carries ``fp``'s unit; ``left`` / ``right`` (the values outside [xp[0], xp[-1]]) are honoured; ``period`` is not
+    supported (no call site of the reference uses any of the three)."""
+    left, right = kwargs.pop("left", None), kwargs.pop("right", None)
+    if kwargs.pop("period", None) is not None or kwargs:
+        raise NotImplementedError("sputils.interp on the GPU: numpy.interp's period / %s not supported" % sorted(kwargs))
     io = _Io()
-    xd, xpd, fpd = io.dev(x), io.dev(xp), io.dev(fp)
+    ux, ufp = _unit(x), _unit(fp)
+    xd, xpd, fpd = io.dev(x), io.dev(xp, unit=ux), io.dev(fp)
     scalar = xd.dim() == 0
     if scalar:
         xd = xd.reshape(1)
     r = io.eng.interp(xd, xpd, fpd)
-    return io.back(r[..., 0] if scalar else r, scalar=scalar and r.dim() == 1)
+    if left is not None or right is not None:        # two selects behind the kernel (NaN abscissae keep the kernel's NaN)
+        with io.eng.on_stream():
+            lo, hi = xpd[..., :1], xpd[..., -1:]
+            if left is not None:
+                r = torch.where(xd < lo, torch.as_tensor(float(_num(left)), dtype=r.dtype, device=r.device), r)
+            if right is not None:
+                r = torch.where(xd > hi, torch.as_tensor(float(_num(right)), dtype=r.dtype, device=r.device), r)
+    return _with_unit(io.back(r[..., 0] if scalar else r, scalar=scalar and r.dim() == 1), ufp)
 
 
 def searchsorted(a, v, **kwargs):
@@ -104,7 +135,7 @@ def searchsorted(a, v, **kwargs):
     if kwargs:
         raise NotImplementedError("sputils.searchsorted on the GPU: numpy.searchsorted's %s not supported" % sorted(kwargs))
     io = _Io()
-    ad, vd = io.dev(a), io.dev(v)
+    ad, vd = io.dev(a), io.dev(v, unit=_unit(a))                      # v.value_in(a.unit), splib/sputils.py:91
     scalar = vd.dim() == 0
     if scalar:
         vd = vd.reshape(1)
@@ -119,6 +150,8 @@ def integral(a, b, z, q, w=None):
     io = _Io()
     ad, bd = io.dev(a), io.dev(b)
     scalar = ad.dim() == 0 and bd.dim() == 0
+    if not scalar:                                                       # one end point given for all rows: broadcast
+        ad, bd = torch.broadcast_tensors(ad.reshape(-1) if ad.dim() else ad.reshape(1), bd.reshape(-1) if bd.dim() else bd.reshape(1))
     Zh = torch.stack([bd.reshape(-1), ad.reshape(-1)], dim=1)            # layer k = [Zh[k+1], Zh[k]] = [a, b]
     zd, qd = io.dev(z), io.dev(q)
     wd = io.dev(w) if w is not None else None

@@ -190,9 +190,21 @@ def test_integral_like_the_reference(sputils):
 def test_rms_rows_in_numpy_order(sputils):
     rng = numpy.random.default_rng(9)
     a = rng.normal(size=(33, 160)) * rng.uniform(1e-3, 1e3, size=(33, 1))
-    assert_bits("rms rows", sputils.rms(a), numpy.array([orc.rms(a[r]) for r in range(33)]))
+    assert_bits("rms rows", sputils.rms(a, axis=-1), numpy.array([orc.rms(a[r]) for r in range(33)]))
     long = rng.normal(size=20011)                                              # > 8192: numpy's chunked pairwise order
     assert sputils.rms(long) == orc.rms(long)
+    assert sputils.rms(a) == numpy.sqrt(numpy.mean(a ** 2))                    # the reference's semantics: ONE number
+    cube = rng.normal(size=(16, 16, 40))                                       # e.g. a 3-D LES field
+    assert sputils.rms(cube) == numpy.sqrt(numpy.mean(cube ** 2))
+
+
+def test_interp_left_right_on_the_device(sputils):
+    rng = numpy.random.default_rng(10)
+    xp = numpy.sort(rng.uniform(0, 100, size=(50, 91)), axis=1)
+    fp, x = rng.normal(size=(50, 91)), rng.uniform(-30, 130, size=(50, 160))
+    for kw in ({"left": -7.5}, {"right": 9.25}, {"left": 0.0, "right": numpy.inf}):
+        want = numpy.stack([numpy.interp(x[r], xp[r], fp[r], **kw) for r in range(50)])
+        assert_bits("interp %s" % kw, sputils.interp(x, xp, fp, **kw), want)
 
 
 def test_float32_engine_runs_the_helpers():

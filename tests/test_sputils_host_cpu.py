@@ -16,11 +16,30 @@ def su():
     spcpl.set_engine(None)
 
 
+class Unit:
+    """a length unit with a factor to metres: just enough of an AMUSE unit for `number | unit` and `value_in`"""
+
+    __array_priority__ = 100           # as amuse.units.core.unit: `ndarray | unit` defers to __ror__
+
+    def __init__(self, name, factor):
+        self.name, self.factor = name, factor
+
+    def __ror__(self, number):
+        return Quantity(number, self)
+
+
 class Quantity:
     """the part of an AMUSE quantity the helpers touch"""
 
-    def __init__(self, number):
+    def __init__(self, number, unit=None):
         self.number = numpy.asarray(number)
+        self.unit = unit
+
+    def value_in(self, unit):
+        return self.number * (self.unit.factor / unit.factor)
+
+
+M, KM, KELVIN = Unit("m", 1.0), Unit("km", 1000.0), Unit("K", 1.0)
 
 
 def test_reference_sputils_test_file_through_the_host_layer(su):
@@ -53,13 +72,55 @@ def test_shapes_scalars_views_and_quantities(su):
     idx = su.searchsorted(xp[0], x[0], side="right")
     assert idx.dtype == numpy.int64 and numpy.array_equal(idx, numpy.searchsorted(xp[0], x[0], side="right"))
     assert su.searchsorted(xp[0], 50.0) == numpy.searchsorted(xp[0], 50.0)
-    assert su.rms(numpy.ones((4, 9))).shape == (4,)
+    assert su.rms(numpy.ones((4, 9)), axis=-1).shape == (4,)
     with pytest.raises(NotImplementedError):
-        su.interp(x[0], xp[0], fp[0], left=0.0)
+        su.interp(x[0], xp[0], fp[0], period=360.0)
     with pytest.raises(NotImplementedError):
         su.searchsorted(xp[0], x[0], sorter=None)
     with pytest.raises(ValueError):
         su.interp(numpy.zeros(3), numpy.zeros(4), numpy.zeros(5))
+
+
+def test_rms_is_one_number_over_the_whole_array_like_the_reference(su):
+    """splib/sputils.py:23-24: numpy.sqrt(numpy.mean(a ** 2)) reduces over EVERY axis"""
+    rng = numpy.random.default_rng(5)
+    for shape in ((4, 9), (3, 5, 7), (2, 3, 4, 5)):
+        a = rng.normal(size=shape)
+        r = su.rms(a)
+        assert numpy.ndim(r) == 0 and r == numpy.sqrt(numpy.mean(a ** 2)), shape
+    a = rng.normal(size=(6, 11))
+    assert numpy.array_equal(su.rms(a, axis=-1), numpy.array([numpy.sqrt(numpy.mean(r ** 2)) for r in a]))
+    with pytest.raises(ValueError):
+        su.rms(rng.normal(size=(2, 3, 4)), axis=0)
+
+
+def test_interp_left_right_like_numpy(su):
+    rng = numpy.random.default_rng(6)
+    xp = numpy.sort(rng.uniform(0, 100, size=(4, 10)), axis=1)
+    fp = rng.normal(size=(4, 10))
+    x = rng.uniform(-30, 130, size=(4, 25))
+    x[1, 3], x[2, 4], x[3, 5] = xp[1, 0], xp[2, -1], numpy.nan             # exactly on the ends: inside; NaN stays NaN
+    for kw in ({"left": -7.5}, {"right": 9.25}, {"left": 0.0, "right": numpy.inf}):
+        want = numpy.stack([numpy.interp(x[r], xp[r], fp[r], **kw) for r in range(4)])
+        assert numpy.array_equal(su.interp(x, xp, fp, **kw), want, equal_nan=True), kw
+        assert numpy.array_equal(su.interp(x[0], xp[0], fp[0], **kw), want[0]), kw
+    assert su.interp(-1e9, xp[0], fp[0], left=3.0) == 3.0 and su.interp(50.0, xp[0], fp[0], left=3.0) == numpy.interp(50.0, xp[0], fp[0])
+
+
+def test_quantities_are_converted_and_keep_their_unit(su):
+    """splib/sputils.py:82-91: xp.value_in(x.unit), v.value_in(a.unit), result | fp.unit -- kilometres against metres must
+    not be compared number against number"""
+    rng = numpy.random.default_rng(7)
+    xp_m = numpy.sort(rng.uniform(0, 4000, size=12))
+    fp, x_m = rng.normal(size=12) + 290, rng.uniform(0, 4000, size=9)
+    want = numpy.interp(x_m, xp_m / 1000.0 * 1000.0, fp)
+    got = su.interp(Quantity(x_m, M), Quantity(xp_m / 1000.0, KM), Quantity(fp, KELVIN))
+    assert isinstance(got, Quantity) and got.unit is KELVIN and numpy.array_equal(got.number, want)
+    assert not isinstance(su.interp(x_m, xp_m, fp), Quantity)
+    idx = su.searchsorted(Quantity(xp_m, M), Quantity(x_m / 1000.0, KM), side="right")
+    assert numpy.array_equal(idx, numpy.searchsorted(xp_m, x_m / 1000.0 * 1000.0, side="right"))
+    r = su.rms(Quantity(fp, KELVIN))
+    assert isinstance(r, Quantity) and r.unit is KELVIN and r.number == numpy.sqrt(numpy.mean(fp ** 2))
 
 
 def test_integral_interp_c_interp_rho_semantics(su, capsys):
@@ -77,6 +138,8 @@ def test_integral_interp_c_interp_rho_semantics(su, capsys):
     got = su.integral(a, b, z, q, w)
     want = numpy.array([numpy.nan if i == 4 else orc.integral(a[i], b[i], z, q, w) for i in range(9)])
     assert numpy.array_equal(got, want, equal_nan=True)
+    got = su.integral(z[2], b, z, q, w)                                      # ONE lower end point for all rows: broadcast
+    assert numpy.array_equal(got, numpy.array([orc.integral(z[2], b[i], z, q, w) for i in range(9)]))
     Zh = numpy.linspace(z[-1] * 1.2, z[0], 8)
     assert numpy.array_equal(su.interp_c(Zh, z, q, w), orc.interp_c(Zh, z, q, w))
     assert numpy.array_equal(su.interp_rho(Zh, z, w), orc.interp_rho(Zh, z, w))

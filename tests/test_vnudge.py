@@ -248,6 +248,48 @@ def test_variance_forcing_through_set_les_forcings_like_splib_step():
         assert (r["status"] != 0).any()
 
 
+def _chunked_vs_one_launch(monkeypatch, n_les, chunk, itot, nL):
+    """spcpl.variability_nudge_batched on n_les LES, once in one launch and once in ceil(n_les / chunk) launches: same
+    random stream, same bits (columns are independent; the reference loops over any number of LES, spcpl.py:377-382)"""
+    from sp_coupler_amd import spcpl
+    runs = []
+    for limit in (32767, chunk):
+        monkeypatch.setattr(spcpl, "VN_MAX_COLS", limit)
+        les = [FieldLES(make_les_fields(itot, itot, nL, seed=70 + i), make_les_fields(itot, itot, nL, seed=70 + i)["ql_ref"], i + 1)
+               for i in range(n_les)]
+        numpy.random.seed(3)
+        out = spcpl.variability_nudge_batched(les, 900.0, constantT=True, write=False)
+        runs.append((out, [m.fields.QT for m in les], [m.fields.THL for m in les]))
+    (o1, q1, t1), (o2, q2, t2) = runs
+    for i in range(n_les):
+        for k in ("beta", "alpha", "qt_std", "a", "status"):
+            assert numpy.array_equal(o1[i][k], o2[i][k], equal_nan=True), (i, k)
+        assert numpy.array_equal(q1[i], q2[i]) and numpy.array_equal(t1[i], t2[i]), i
+    assert any((o["status"] != 0).any() for o in o1)
+
+
+def test_nudge_in_chunks_gives_the_bits_of_one_launch_host_logic(monkeypatch):
+    """CPU, oracle-backed test engine: 5 LES in chunks of 2 (three launches)"""
+    from sp_coupler_amd import spcpl
+    from tests.fake_engine import OracleEngine
+    spcpl.set_engine(OracleEngine())
+    try:
+        _chunked_vs_one_launch(monkeypatch, 5, 2, 8, 24)
+    finally:
+        spcpl.set_engine(None)
+
+
+@pytest.mark.gpu
+def test_nudge_in_chunks_gives_the_bits_of_one_launch_on_the_gpu(monkeypatch):
+    """K6: 7 LES of 16 x 16 x 40 in chunks of 3 (three launches, the last one short)"""
+    from sp_coupler_amd import spcpl
+    spcpl.set_engine(None)
+    try:
+        _chunked_vs_one_launch(monkeypatch, 7, 3, 16, 40)
+    finally:
+        spcpl.set_engine(None)
+
+
 def _load_vnudge_golden():
     import os
     z = numpy.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vnudge_small.npz"))   # no pickle

@@ -3,31 +3,33 @@
 #pragma once
 
 // ---- host side ----------------------------------------------------------------------------------
-inline unsigned su_grid(int64_t items, int per_block, unsigned cap)
-{
-    const int64_t g = (items + per_block - 1) / per_block;
-    return (unsigned)(g < 1 ? 1 : (g > (int64_t)cap ? cap : g));
-}
+// write-through stores for launches that leave <= 32 MiB behind (small_batch, as K1 / K3)
+#define SU_PICK_WT(KERN_WT1, KERN_WT0, bytes) (small_batch((int64_t)(bytes)) ? (KERN_WT1) : (KERN_WT0))
 
 template <typename T> int exner_impl(int64_t n, const void *p, void *out, int inverse, void *stream)
 {
     if (n < 0) return fail(SPC_ERR_INVALID_ARGUMENT, "%sexner: n < 0");
     if (n == 0) return SPC_OK;
     REQUIRE(p, "p"); REQUIRE(out, "out");
-    hipLaunchKernelGGL(k_exner<T>, dim3(su_grid(n, SU_THREADS, 256 * 16)), dim3(SU_THREADS), 0, (hipStream_t)stream, n,
-                       (const T *)p, (T *)out, inverse);
+    const int64_t per = (int64_t)SU_THREADS * 4;
+    if ((n + per - 1) / per > 0x7fffffff) return fail(SPC_ERR_UNSUPPORTED, "%sexner: more than 2^41 elements");
+    auto kern = SU_PICK_WT((k_exner<T, 1>), (k_exner<T, 0>), n * (int64_t)sizeof(T));
+    hipLaunchKernelGGL(kern, dim3((unsigned)((n + per - 1) / per)), dim3(SU_THREADS), 0, (hipStream_t)stream, n, (const T *)p, (T *)out, inverse);
     return launch_status("k_exner");
 }
 
-// rows per workgroup: enough to give the workgroup's threads two outputs each (measured over 1, 2, 4, 8 at 35 718 rows: 2 is the fastest or within 3 %; fewer
-// workgroups; SPC_SU_ITEMS overrides for A/B runs), within the LDS budget
-inline int su_rows_per_block(int n_out, size_t lds_per_row, size_t lds_fixed, size_t esize, int *stage)
+// Rows per workgroup (the slab): enough rows for ~`target` outputs per workgroup -- 4-5 per thread, the shape of K1's
+// 8-column slabs -- within the LDS budget, but never so many that the grid drops under four workgroups per CU (small
+// batches are latency-bound: more, smaller workgroups).  SPC_SU_TARGET overrides for A/B runs.
+inline int su_rows(int64_t n_rows, int n_out, size_t lds_per_row, size_t lds_fixed, size_t esize, int *stage)
 {
-    static const int items = [] { const char *e = getenv("SPC_SU_ITEMS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }();
-    int rb = n_out > 0 ? (SU_THREADS * items + n_out - 1) / n_out : 1;
+    static const int target = [] { const char *e = getenv("SPC_SU_TARGET"); const int v = e ? atoi(e) : 1100; return v < 1 ? 1 : v; }();
+    int rb = n_out > 0 ? (target + n_out - 1) / n_out : 1;
     if (rb < 1) rb = 1;
     if (rb > 64) rb = 64;
-    while (rb > 1 && (lds_per_row * rb + lds_fixed) * esize > SU_MAX_LDS) --rb;
+    const int64_t most = n_rows / 1024;                     // >= 1024 workgroups = 4 per CU
+    if (rb > most) rb = most < 1 ? 1 : (int)most;
+    while (rb > 1 && (lds_per_row * rb + lds_fixed) * esize > (size_t)16 * 1024) --rb;      // 16 KiB: >= 8 workgroups per CU
     *stage = (lds_per_row * rb + lds_fixed) * esize <= SU_MAX_LDS;
     return rb;
 }
@@ -44,10 +46,15 @@ template <typename T> int interp_impl(const spc_interp_args *a, void *stream)
     SuInterpP q;
     q.n_rows = a->n_rows; q.pitch_x = a->pitch_x; q.pitch_xp = a->pitch_xp; q.pitch_fp = a->pitch_fp; q.pitch_out = a->pitch_out;
     q.n_x = a->n_x; q.n_xp = a->n_xp; q.p2 = floor_pow2(a->n_xp);
-    q.rb = su_rows_per_block(a->n_x, (size_t)a->n_xp * (a->pitch_xp ? 2 : 1), a->pitch_xp ? 0 : a->n_xp, sizeof(T), &q.stage);
+    int stage;
+    q.rb = su_rows(a->n_rows, a->n_x, (size_t)a->n_xp * (a->pitch_xp ? 2 : 1), a->pitch_xp ? 0 : a->n_xp, sizeof(T), &stage);
+    if ((a->n_rows + q.rb - 1) / q.rb > 0x7fffffff) return fail(SPC_ERR_UNSUPPORTED, "%sinterp: too many rows for one launch");
     q.x = a->x; q.xp = a->xp; q.fp = a->fp; q.out = a->out;
-    const size_t smem = q.stage ? ((size_t)a->n_xp * (a->pitch_xp ? 2 : 1) * q.rb + (a->pitch_xp ? 0 : a->n_xp)) * sizeof(T) : 0;
-    hipLaunchKernelGGL(k_interp<T>, dim3((unsigned)((a->n_rows + q.rb - 1) / q.rb)), dim3(SU_THREADS), smem, (hipStream_t)stream, q);
+    const size_t smem = stage ? ((size_t)a->n_xp * (a->pitch_xp ? 2 : 1) * q.rb + (a->pitch_xp ? 0 : a->n_xp)) * sizeof(T) : 0;
+    const int64_t wr = a->n_rows * (int64_t)a->n_x * (int64_t)sizeof(T);
+    void (*kern)(const SuInterpP) = stage ? SU_PICK_WT((k_interp<T, true, 1>), (k_interp<T, true, 0>), wr)
+                                          : SU_PICK_WT((k_interp<T, false, 1>), (k_interp<T, false, 0>), wr);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((a->n_rows + q.rb - 1) / q.rb)), dim3(SU_THREADS), smem, (hipStream_t)stream, q);
     return launch_status("k_interp");
 }
 
@@ -63,11 +70,28 @@ template <typename T> int searchsorted_impl(const spc_searchsorted_args *a, void
     SuSearchP q;
     q.n_rows = a->n_rows; q.pitch_a = a->pitch_a; q.pitch_v = a->pitch_v; q.pitch_out = a->pitch_out;
     q.n_a = a->n_a; q.n_v = a->n_v; q.right = a->side_right != 0;
-    q.rb = su_rows_per_block(a->n_v, a->pitch_a ? a->n_a : 0, a->pitch_a ? 0 : a->n_a, sizeof(T), &q.stage);
+    int stage;
+    q.rb = su_rows(a->n_rows, a->n_v, a->pitch_a ? a->n_a : 0, a->pitch_a ? 0 : a->n_a, sizeof(T), &stage);
+    if ((a->n_rows + q.rb - 1) / q.rb > 0x7fffffff) return fail(SPC_ERR_UNSUPPORTED, "%ssearchsorted: too many rows for one launch");
     q.a = a->a; q.v = a->v; q.out = a->out;
-    const size_t smem = q.stage ? ((size_t)(a->pitch_a ? a->n_a : 0) * q.rb + (a->pitch_a ? 0 : a->n_a)) * sizeof(T) : 0;
-    hipLaunchKernelGGL(k_searchsorted<T>, dim3((unsigned)((a->n_rows + q.rb - 1) / q.rb)), dim3(SU_THREADS), smem, (hipStream_t)stream, q);
+    const size_t smem = stage ? ((size_t)(a->pitch_a ? a->n_a : 0) * q.rb + (a->pitch_a ? 0 : a->n_a)) * sizeof(T) : 0;
+    const int64_t wr = a->n_rows * (int64_t)a->n_v * 8;
+    void (*kern)(const SuSearchP) = stage ? SU_PICK_WT((k_searchsorted<T, true, 1>), (k_searchsorted<T, true, 0>), wr)
+                                          : SU_PICK_WT((k_searchsorted<T, false, 1>), (k_searchsorted<T, false, 0>), wr);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((a->n_rows + q.rb - 1) / q.rb)), dim3(SU_THREADS), smem, (hipStream_t)stream, q);
     return launch_status("k_searchsorted");
+}
+
+// the instantiation of k_interp_c for (PD, STAGE, WEIGHTED, WT); the unrolled depths exist for the staged double kernel
+template <typename T, bool STAGE, bool W, int WT> auto interp_c_kernel(int pd) -> void (*)(const SuCoarseP)
+{
+    if constexpr (sizeof(T) == 8 && STAGE) {
+        if (pd == 1) return k_interp_c<T, 1, STAGE, W, WT>;
+        if (pd == 2) return k_interp_c<T, 2, STAGE, W, WT>;
+        if (pd == 3) return k_interp_c<T, 3, STAGE, W, WT>;
+    }
+    (void)pd;
+    return k_interp_c<T, -1, STAGE, W, WT>;
 }
 
 template <typename T> int interp_c_impl(const spc_interp_c_args *a, void *stream)
@@ -86,15 +110,21 @@ template <typename T> int interp_c_impl(const spc_interp_c_args *a, void *stream
     q.n_rows = a->n_rows; q.pitch_Zh = a->pitch_Zh; q.pitch_zh = a->pitch_zh; q.pitch_q = a->pitch_q; q.pitch_out = a->pitch_out;
     q.nG = a->nG; q.nL = a->nL; q.mode = a->mode;
     q.Zh = a->Zh; q.zh = a->zh; q.q = a->q; q.rho = a->mode == SU_INTERP_RHO ? nullptr : a->rho; q.out = a->out;
-    q.rb = su_rows_per_block(a->nG, (size_t)a->nL * (a->pitch_zh ? 3 : 2), a->pitch_zh ? 0 : a->nL, sizeof(T), &q.stage);
-    const size_t smem = q.stage ? ((size_t)a->nL * (a->pitch_zh ? 3 : 2) * q.rb + (a->pitch_zh ? 0 : a->nL)) * sizeof(T) : 0;
+    const bool weighted = q.rho != nullptr;
+    // LDS per row: the cell terms tn (and td with weights) [nL - 1] + the row's grid [nL] unless it is shared
+    const size_t per_row = (size_t)(a->nL - 1) * (weighted ? 2 : 1) + (a->pitch_zh ? a->nL : 0);
+    int stage;
+    q.rb = su_rows(a->n_rows, a->nG, per_row, a->pitch_zh ? 0 : a->nL, sizeof(T), &stage);
+    const size_t smem = stage ? (per_row * q.rb + (a->pitch_zh ? 0 : a->nL)) * sizeof(T) : 0;
     // numpy's pairwise recursion unrolled to the depth a layer of <= nL - 1 cells needs (cons_depth, as K4); the float twin
     // and grids of more than 1024 points keep the explicit stack
     const int pd = sizeof(T) == 8 ? cons_depth(a->nL) : -1;
-    void (*kern)(const SuCoarseP) = q.stage ? k_interp_c<T, -1, true> : k_interp_c<T, -1, false>;
-    if constexpr (sizeof(T) == 8) {
-        if (q.stage) kern = pd == 1 ? k_interp_c<T, 1, true> : pd == 2 ? k_interp_c<T, 2, true> : pd == 3 ? k_interp_c<T, 3, true> : kern;
-    }
+    const bool wt = small_batch(a->n_rows * (int64_t)a->nG * (int64_t)sizeof(T)) != 0;
+    void (*kern)(const SuCoarseP);
+    if (stage) kern = weighted ? (wt ? interp_c_kernel<T, true, true, 1>(pd) : interp_c_kernel<T, true, true, 0>(pd))
+                               : (wt ? interp_c_kernel<T, true, false, 1>(pd) : interp_c_kernel<T, true, false, 0>(pd));
+    else kern = weighted ? (wt ? interp_c_kernel<T, false, true, 1>(pd) : interp_c_kernel<T, false, true, 0>(pd))
+                         : (wt ? interp_c_kernel<T, false, false, 1>(pd) : interp_c_kernel<T, false, false, 0>(pd));
     hipLaunchKernelGGL(kern, dim3((unsigned)((a->n_rows + q.rb - 1) / q.rb)), dim3(SU_THREADS), smem, (hipStream_t)stream, q);
     return launch_status("k_interp_c");
 }
@@ -107,7 +137,12 @@ template <typename T> int rms_impl(int64_t n_rows, int64_t n, int64_t pitch, con
     REQUIRE(out, "out");
     if (n) REQUIRE(a, "a");
     if (pitch < n) return fail(SPC_ERR_INVALID_ARGUMENT, "%srms: pitch smaller than the row");
-    hipLaunchKernelGGL(k_rms<T>, dim3((unsigned)((n_rows + 63) / 64)), dim3(64), 0, (hipStream_t)stream, n_rows, (int)n, pitch,
-                       (const T *)a, (T *)out);
+    const int64_t grid = (n_rows + SU_THREADS / 8 - 1) / (SU_THREADS / 8);
+    if (grid > 0x7fffffff) return fail(SPC_ERR_UNSUPPORTED, "%srms: too many rows for one launch");
+    // depth of numpy's recursion over one row (a single chunk up to 8192 elements); -1: explicit stack, any length
+    const int pd = n <= 128 ? 0 : (n <= 1024 ? cons_depth((int)n) : -1);
+    void (*kern)(int64_t, int, int64_t, const T *, T *) =
+        pd == 0 ? k_rms<T, 0, 1> : pd == 1 ? k_rms<T, 1, 1> : pd == 2 ? k_rms<T, 2, 1> : pd == 3 ? k_rms<T, 3, 1> : k_rms<T, -1, 1>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(SU_THREADS), 0, (hipStream_t)stream, n_rows, (int)n, pitch, (const T *)a, (T *)out);
     return launch_status("k_rms");
 }

@@ -161,6 +161,22 @@ class SurfacePlan(_Plan):
         return "k_surface"
 
 
+class OperatorPlan(_Plan):
+    """a K7 operator (exner / interp / searchsorted / interp_c / rms) with its arguments frozen: ``run()`` launches and
+    returns the result tensor (the caller's ``out=`` or the one allocated when the plan was made)"""
+
+    def __init__(self, engine, fn, call_args, keep, outputs, result):
+        super().__init__(engine, fn, call_args, keep, outputs)
+        self.result = result
+
+    def run(self, stream=None):
+        self.launch(stream)
+        return self.result
+
+    def describe(self):
+        return getattr(self._fn, "__name__", "operator")
+
+
 class Engine:
     """One engine per (device, dtype). ``dtype`` is the arithmetic type of the path: float64 as in
     the reference (AMUSE quantities wrap float64 arrays), float32 for the tolerance sweep."""
@@ -495,6 +511,9 @@ class Engine:
         return res
 
     # -- K7: the helpers of splib/sputils.py as batched operators (sp_coupler_amd/sputils.py keeps their names) -------
+    # Each operator has a ``plan_*`` form (arguments checked and the C argument block frozen ONCE, output allocated once
+    # or taken from ``out=``: ``plan.run()`` is then one foreign call, no allocation) and a convenience form that builds
+    # the plan and runs it.
     def _rows(self, name, t, n_rows=None, shared_ok=False):
         """(tensor, data_ptr, pitch, n): a [n_rows x n] matrix contiguous along n (pitch = row stride), or -- where the
         operator allows it -- ONE [n] row shared by all rows (pitch 0)"""
@@ -515,26 +534,47 @@ class Engine:
             t = t.contiguous()
         return t, t.data_ptr(), (int(t.stride(0)) if t.shape[0] > 1 else max(1, int(t.shape[1]))), int(t.shape[1])
 
+    def _out(self, out, n_rows, n, dtype=None):
+        """the operator's [n_rows x n] result: the caller's ``out`` (checked; may be [n] when n_rows == 1, may be pitched)
+        or a fresh tensor.  Returns (2-D tensor, pitch)."""
+        dtype = dtype or self.dtype
+        if out is None:
+            out = torch.empty(n_rows, n, dtype=dtype, device=self.device)
+        else:
+            if not isinstance(out, torch.Tensor) or out.device != self.device or out.dtype != dtype:
+                raise ValueError("out must be a %s tensor on %s" % (dtype, self.device))
+            if out.dim() == 1 and n_rows == 1:
+                out = out.unsqueeze(0)
+            if tuple(out.shape) != (n_rows, n) or (n > 1 and out.stride(1) != 1) or (n_rows > 1 and out.stride(0) < n):
+                raise ValueError("out must be [%d x %d], contiguous along its rows, got %s (strides %s)"
+                                 % (n_rows, n, tuple(out.shape), out.stride()))
+        return out, (int(out.stride(0)) if n_rows > 1 else max(1, n))
+
     def _call(self, fn, *args, stream=None):
         with torch.cuda.device(self.device):
             rc = fn(*args, _stream_ptr(stream if stream is not None else self.stream, self.device))
         _abi.check(self.lib, rc)
 
     @_on_engine_stream
-    def exner(self, p, inverse=False, stream=None):
+    def plan_exner(self, p, inverse=False, out=None):
         """sputils.exner / iexner (splib/sputils.py:28-34), elementwise on a device tensor of any shape"""
         if p.device != self.device or p.dtype != self.dtype:
             raise ValueError("p must be %s on %s" % (self.dtype, self.device))
         p = p.contiguous()
-        out = torch.empty_like(p)
-        self._call(getattr(self.lib, "spc_exner_" + _DTYPES[self.dtype]), p.numel(), p.data_ptr(), out.data_ptr(), 1 if inverse else 0,
-                   stream=stream)
-        return out
+        if out is None:
+            out = torch.empty_like(p)
+        elif not isinstance(out, torch.Tensor) or out.device != self.device or out.dtype != self.dtype or out.shape != p.shape or not out.is_contiguous():
+            raise ValueError("out must be a contiguous %s tensor of shape %s on %s" % (self.dtype, tuple(p.shape), self.device))
+        fn = getattr(self.lib, "spc_exner_" + _DTYPES[self.dtype])
+        return OperatorPlan(self, fn, (p.numel(), p.data_ptr(), out.data_ptr(), 1 if inverse else 0), [p, out], {"out": out}, result=out)
+
+    def exner(self, p, inverse=False, stream=None, out=None):
+        return self.plan_exner(p, inverse, out=out).run(stream)
 
     @_on_engine_stream
-    def interp(self, x, xp, fp, stream=None):
+    def plan_interp(self, x, xp, fp, out=None):
         """sputils.interp == numpy.interp (splib/sputils.py:82-86) for every row: fp [n_rows x n_xp] (or [n_xp]), xp the
-        same shape or one shared [n_xp], x [n_rows x n_x] or one shared [n_x].  Returns [n_rows x n_x] ([n_x] when every
+        same shape or one shared [n_xp], x [n_rows x n_x] or one shared [n_x].  Result [n_rows x n_x] ([n_x] when every
         argument is 1-D)."""
         one = fp.dim() == 1 and xp.dim() == 1 and x.dim() == 1
         n_rows = max(int(t.shape[0]) if t.dim() == 2 else 1 for t in (x, xp, fp))
@@ -544,13 +584,16 @@ class Engine:
         x2, p_x, pitch_x, n_x = self._rows("x", x, n_rows, shared_ok=True)
         if n_xp2 != n_xp:
             raise ValueError("fp and xp are not of the same length")          # numpy.interp's message
-        out = self.empty(n_rows, n_x)
-        a = _abi.InterpArgs(n_rows, n_x, n_xp, pitch_x, pitch_xp, pitch_fp, max(1, n_x), p_x, p_xp, p_fp, out.data_ptr())
-        self._call(getattr(self.lib, "spc_interp_" + _DTYPES[self.dtype]), ctypes.byref(a), stream=stream)
-        return out[0] if one else out
+        out, pitch_out = self._out(out, n_rows, n_x)
+        a = _abi.InterpArgs(n_rows, n_x, n_xp, pitch_x, pitch_xp, pitch_fp, pitch_out, p_x, p_xp, p_fp, out.data_ptr())
+        fn = getattr(self.lib, "spc_interp_" + _DTYPES[self.dtype])
+        return OperatorPlan(self, fn, (ctypes.byref(a),), [fp2, xp2, x2, out, a], {"out": out}, result=out[0] if one else out)
+
+    def interp(self, x, xp, fp, stream=None, out=None):
+        return self.plan_interp(x, xp, fp, out=out).run(stream)
 
     @_on_engine_stream
-    def searchsorted(self, a, v, side="left", stream=None):
+    def plan_searchsorted(self, a, v, side="left", out=None):
         """sputils.searchsorted == numpy.searchsorted (splib/sputils.py:88-91) per row; int64 indices"""
         if side not in ("left", "right"):
             raise ValueError("side must be 'left' or 'right'")
@@ -558,13 +601,16 @@ class Engine:
         n_rows = max(int(t.shape[0]) if t.dim() == 2 else 1 for t in (a, v))
         a2, p_a, pitch_a, n_a = self._rows("a", a, n_rows, shared_ok=True)
         v2, p_v, pitch_v, n_v = self._rows("v", v, n_rows, shared_ok=True)
-        out = torch.empty(n_rows, n_v, dtype=torch.int64, device=self.device)
-        args = _abi.SearchsortedArgs(n_rows, n_a, n_v, pitch_a, pitch_v, max(1, n_v), p_a, p_v, out.data_ptr(), 1 if side == "right" else 0, 0)
-        self._call(getattr(self.lib, "spc_searchsorted_" + _DTYPES[self.dtype]), ctypes.byref(args), stream=stream)
-        return out[0] if one else out
+        out, pitch_out = self._out(out, n_rows, n_v, dtype=torch.int64)
+        args = _abi.SearchsortedArgs(n_rows, n_a, n_v, pitch_a, pitch_v, pitch_out, p_a, p_v, out.data_ptr(), 1 if side == "right" else 0, 0)
+        fn = getattr(self.lib, "spc_searchsorted_" + _DTYPES[self.dtype])
+        return OperatorPlan(self, fn, (ctypes.byref(args),), [a2, v2, out, args], {"out": out}, result=out[0] if one else out)
+
+    def searchsorted(self, a, v, side="left", stream=None, out=None):
+        return self.plan_searchsorted(a, v, side, out=out).run(stream)
 
     @_on_engine_stream
-    def interp_c(self, Zh, zh, q, rho=None, mode="interp_c", stream=None):
+    def plan_interp_c(self, Zh, zh, q, rho=None, mode="interp_c", out=None):
         """sputils.interp_c / interp_rho / integral (splib/sputils.py:94-197) per row: Zh [n_rows x (nG+1)] layer bounds, zh
         [nL] (shared) or [n_rows x nL] grid points, q (and rho) [n_rows x nL'] with nL' >= nL - 1 cell values.
         mode 'interp_c' (rho required), 'interp_rho' (q is the density), 'integral' (rho optional)."""
@@ -578,7 +624,7 @@ class Engine:
         q2, p_q, pitch_q, nq = self._rows("q", q, n_rows)
         if nq < nL - 1:
             raise ValueError("q has %d values, the %d grid points of zh bound %d cells" % (nq, nL, nL - 1))
-        p_rho = None
+        p_rho, rho2 = None, None
         if rho is not None and mode != "interp_rho":
             rho2, p_rho, pitch_rho, nr = self._rows("rho", rho, n_rows)
             if nr != nq:
@@ -589,20 +635,30 @@ class Engine:
         elif mode == "interp_c":
             raise ValueError("interp_c needs the weights rho")
         nG = nGh - 1
-        out = self.empty(n_rows, max(nG, 0))
-        a = _abi.InterpCArgs(n_rows, nG, nL, pitch_Zh, pitch_zh, pitch_q, max(1, nG), p_Zh, p_zh, p_q, p_rho, out.data_ptr(), modes[mode], 0)
-        self._call(getattr(self.lib, "spc_interp_c_" + _DTYPES[self.dtype]), ctypes.byref(a), stream=stream)
-        return out[0] if one else out
+        out, pitch_out = self._out(out, n_rows, max(nG, 0))
+        a = _abi.InterpCArgs(n_rows, nG, nL, pitch_Zh, pitch_zh, pitch_q, pitch_out, p_Zh, p_zh, p_q, p_rho, out.data_ptr(), modes[mode], 0)
+        fn = getattr(self.lib, "spc_interp_c_" + _DTYPES[self.dtype])
+        return OperatorPlan(self, fn, (ctypes.byref(a),), [Zh2, zh2, q2, rho2, out, a], {"out": out}, result=out[0] if one else out)
+
+    def interp_c(self, Zh, zh, q, rho=None, mode="interp_c", stream=None, out=None):
+        return self.plan_interp_c(Zh, zh, q, rho, mode, out=out).run(stream)
 
     @_on_engine_stream
-    def rms(self, a, stream=None):
+    def plan_rms(self, a, out=None):
         """sputils.rms (splib/sputils.py:23-24) of every row of a [n_rows x n] tensor (of the one row of a 1-D tensor)"""
         one = a.dim() == 1
         a2, p_a, pitch, n = self._rows("a", a)
         n_rows = 1 if one else int(a2.shape[0])
-        out = self.empty(n_rows)
-        self._call(getattr(self.lib, "spc_rms_" + _DTYPES[self.dtype]), n_rows, n, max(pitch, n), p_a, out.data_ptr(), stream=stream)
-        return out[0] if one else out
+        if out is None:
+            out = self.empty(n_rows)
+        elif not isinstance(out, torch.Tensor) or out.device != self.device or out.dtype != self.dtype or tuple(out.shape) != (n_rows,) \
+                or not out.is_contiguous():
+            raise ValueError("out must be a contiguous %s vector of %d on %s" % (self.dtype, n_rows, self.device))
+        fn = getattr(self.lib, "spc_rms_" + _DTYPES[self.dtype])
+        return OperatorPlan(self, fn, (n_rows, n, max(pitch, n), p_a, out.data_ptr()), [a2, out], {"out": out}, result=out[0] if one else out)
+
+    def rms(self, a, stream=None, out=None):
+        return self.plan_rms(a, out=out).run(stream)
 
     # -- surface fluxes of columns without an LES -------------------------------------------------
     @_on_engine_stream

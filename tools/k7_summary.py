@@ -16,10 +16,9 @@ ALG = {"k_interp fwd": n * (2 * nG + nL) * 8, "k_interp bwd": n * (nG + nL + nG)
 
 
 def short(name):
-    for k in ("k_interp_c", "k_interp", "k_searchsorted", "k_exner", "k_rms", "k_copy16", "k_copy8"):
-        if name.startswith(k) or (" " + k) in name or ("void " + k) in name:
-            return k
-    return None
+    import re
+    m = re.search(r"(?:^|::|\s)(k_interp_c|k_interp|k_searchsorted|k_exner|k_rms|k_copy16|k_copy8)\b", name)
+    return m.group(1) if m else None
 
 
 def counters(sub):

@@ -75,15 +75,24 @@ def main():
         Zh = dev((gcm["Zghalf"] - gcm["Zghalf"][:, -1:]) / 9.81)
         T_, Pf = dev(gcm["T"][:, ::-1]), dev(gcm["Pfull"])
         zf_d, zh_d, qt, rho = dev(zf), dev(zh), dev(prof["QT"]), dev(prof["Rhobf"])
-        rows = [("interp GCM->LES (x shared [nL], xp/fp per row [nG])", lambda: eng.interp(zf_d, Zf, T_), n * (2 * nG + nL) * 8),
-                ("interp LES->GCM (x per row [nG], xp shared [nL])", lambda: eng.interp(Zf, zf_d, qt), n * (nG + nL + nG) * 8),
-                ("searchsorted(zh, Zh, right)", lambda: eng.searchsorted(zh_d, Zh, side="right"), n * (2 * (nG + 1)) * 8),
-                ("iexner(Pfull)", lambda: eng.exner(Pf, inverse=True), n * 2 * nG * 8),
-                ("interp_c(Zh, zh, qt, rhobf)", lambda: eng.interp_c(Zh, zh_d, qt, rho), n * (nG + 1 + 2 * nL + nG) * 8),
-                ("rms rows [n x nL]", lambda: eng.rms(qt), n * (nL + 1) * 8)]
-        for name, fn, nbytes in rows:
-            t = timed(fn, a.iters)
-            print("n=%d K7 %-52s %8.1f us %6.0f GB/s (algorithmic bytes; the output allocation is inside the call)" % (n, name, t, nbytes / t / 1e3), flush=True)
+        rows = [("interp GCM->LES (x shared [nL], xp/fp per row [nG])", lambda: eng.interp(zf_d, Zf, T_), eng.plan_interp(zf_d, Zf, T_), n * (2 * nG + nL) * 8),
+                ("interp LES->GCM (x per row [nG], xp shared [nL])", lambda: eng.interp(Zf, zf_d, qt), eng.plan_interp(Zf, zf_d, qt), n * (nG + nL + nG) * 8),
+                ("searchsorted(zh, Zh, right)", lambda: eng.searchsorted(zh_d, Zh, side="right"), eng.plan_searchsorted(zh_d, Zh, side="right"), n * (2 * (nG + 1)) * 8),
+                ("iexner(Pfull)", lambda: eng.exner(Pf, inverse=True), eng.plan_exner(Pf, inverse=True), n * 2 * nG * 8),
+                ("interp_c(Zh, zh, qt, rhobf)", lambda: eng.interp_c(Zh, zh_d, qt, rho), eng.plan_interp_c(Zh, zh_d, qt, rho), n * (nG + 1 + 2 * nL + nG) * 8),
+                ("rms rows [n x nL]", lambda: eng.rms(qt), eng.plan_rms(qt), n * (nL + 1) * 8)]
+        import time
+        for name, fn, plan, nbytes in rows:
+            t = timed(fn, a.iters)                      # convenience call: checks + argument block + output allocation per call
+            tp = timed(lambda: plan.launch_raw(sptr), a.iters)     # the plan: one foreign call, output bound once (out=)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                plan.run()
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) / 200 * 1e6         # host + device per call, back to back
+            print("n=%d K7 %-52s call %7.1f us | plan %7.1f us %6.0f GB/s (%.3f of 8 TB/s) | plan.run() wall %6.1f us" % (
+                n, name, t, tp, nbytes / tp / 1e3, nbytes / tp / 1e3 / 8000.0, wall), flush=True)
     from tests.test_vnudge import make_les_fields
     for shape in (x for x in a.vn_shapes.split(",") if x):
         it, jt, kt = (int(v) for v in shape.split("x"))

@@ -57,12 +57,103 @@ template <typename T> struct SuSlab {
     {
         if (flat) return ldg(base + e);
         const int r = e / n, j = e - r * n;
-        return ldg(base + (int64_t)r * pitch + j);
+        return ldg(base + (r * (int)pitch + j));
     }
 };
 template <typename T> __device__ __forceinline__ SuSlab<T> su_slab(const void *p, int64_t row0, int64_t pitch, int n)
 {
     return SuSlab<T>{(const T *)p + row0 * pitch, pitch, n, pitch == (int64_t)n};
+}
+
+// element `off` (a 32-bit count off a wave-uniform base) addressed as base + zero-extended BYTE offset: the form the
+// backend turns into one global_load / global_store with a scalar base and a 32-bit VGPR offset (no 64-bit VALU arithmetic)
+template <typename T> __device__ __forceinline__ const T *su_at(const T *base, int off)
+{
+    return (const T *)((const char *)base + (unsigned)(off * (int)sizeof(T)));
+}
+template <typename T> __device__ __forceinline__ T *su_at(T *base, int off)
+{
+    return (T *)((char *)base + (unsigned)(off * (int)sizeof(T)));
+}
+
+// ---- searches on LDS rows: fixed trip count, no bounds check -------------------------------------------------------
+// The three searches of this file -- numpy.interp's bracket (count of xp[i] <= x), numpy.searchsorted (count of entries
+// in front of the insertion point) and integral()'s cell scan (count of z[k] < a) -- are prefix counts over an ascending
+// row.  A staged row is PADDED WITH NaN up to 2 p2 entries (p2 = the largest power of two <= its length): the greedy
+// power-of-two descent of upper_count() then needs no `t <= n` test, because no predicate used here advances on a NaN
+// (searchsorted with a NaN key is the one exception and clamps), and with the trip count a template argument (SL =
+// log2 p2 + 1) every probe is one ds_read with an immediate offset + compare + select: 3 VALU instructions per step
+// instead of 8-12 (round 4: the first K7 generation was bound by VALU issue, 100-150 instructions per output,
+// profiles/r04_k7_counters.log).  SL = 0: the same descent with p2 at run time; SL = -1: nothing staged (rows beyond
+// the LDS), the operators fall back to the loops on global memory.
+__host__ __device__ inline int su_pad(int p2) { return 2 * p2 + 2; }      // entries of a padded row (+2: rows off each other's banks)
+
+template <int SL, typename T, typename Pred> __device__ __forceinline__ int su_count(const T *row, int p2, const Pred &adv)
+{
+    int pos = 0;
+    if constexpr (SL > 0) {
+#pragma unroll
+        for (int s = 1 << (SL - 1); s > 0; s >>= 1)
+            if (adv(row[pos + s - 1])) pos += s;
+    } else {
+        for (int s = p2; s > 0; s >>= 1)
+            if (adv(row[pos + s - 1])) pos += s;
+    }
+    return pos;
+}
+
+// nrow rows of n elements (row r at src + r * pitch) into LDS rows of `stride` entries, the tail of every row NaN;
+// U entries of a thread in flight before its first LDS store; (row, entry) stepped, never divided
+template <int U, typename T> __device__ __forceinline__ void su_stage_rows(T *dst, int nrow, int n, int stride, int tid, const T *src, int pitch)
+{
+    const int total = nrow * stride;
+    const T nan = T(0) / T(0);
+    int r = tid / stride, j = tid - r * stride;
+    for (int t0 = tid; t0 < total; t0 += SU_THREADS * U) {
+        T v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v[u] = (t0 + u * SU_THREADS < total && j < n) ? ldg(su_at(src, r * pitch + j)) : nan;  // uniform base + 32-bit offset
+            j += SU_THREADS;
+            while (j >= stride) { j -= stride; ++r; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (t0 + u * SU_THREADS < total) dst[t0 + u * SU_THREADS] = v[u];
+    }
+}
+
+// numpy.interp's bracket (as bracket()) on a padded LDS row
+template <int SL, typename T> __device__ __forceinline__ Bracket<T> bracket_pad(const T *xp, int n, int p2, T x)
+{
+    Bracket<T> b;
+    b.x = x;
+    if (n == 1) { b.mode = 1; b.j = 0; b.x0 = b.x1 = x; return b; }   // numpy lenxp == 1: fp[0], NaN x included
+    if (x != x) { b.mode = 2; b.j = 0; b.x0 = b.x1 = x; return b; }
+    const int j = su_count<SL>(xp, p2, [&](T e) { return e <= x; }) - 1;
+    if (j < 0) { b.mode = 1; b.j = 0; b.x0 = b.x1 = x; return b; }                  // x < xp[0] -> fp[0]
+    if (j >= n - 1) { b.mode = 1; b.j = n - 1; b.x0 = b.x1 = x; return b; }         // x >= xp[n-1] -> fp[n-1]
+    b.j = j;
+    b.x0 = xp[j];
+    b.x1 = xp[j + 1];
+    b.mode = (b.x0 == x) ? 1 : 0;                                                   // exact hit -> fp[j]
+    return b;
+}
+
+// interp_at() with numpy's NaN fallbacks kept as a (rare) branch instead of being computed for every lane and selected:
+// the standalone interp is bound by VALU issue (K1 / K3, which are not, keep lerp_np as it is)
+template <typename T> __device__ __forceinline__ T su_interp_at(const Bracket<T> &b, const T *fp)
+{
+    if (b.mode == 2) return b.x;
+    if (b.mode == 1) return fp[b.j];
+    const T f0 = fp[b.j], f1 = fp[b.j + 1];
+    const T slope = (f1 - f0) / (b.x1 - b.x0);
+    T r = slope * (b.x - b.x0) + f0;
+    if (__builtin_expect(r != r, 0)) {
+        r = slope * (b.x - b.x1) + f1;
+        if (r != r && f0 == f1) r = f0;
+    }
+    return r;
 }
 
 // ---- exner ---------------------------------------------------------------------------------------------------------
@@ -93,36 +184,41 @@ struct SuInterpP {
     void *out;
 };
 
-// STAGE: the slab's sample arrays go through LDS: fp[rb][n_xp] | xp[rb][n_xp] (or xp[n_xp] when shared)
-template <typename T, bool STAGE, int WT> __global__ __launch_bounds__(SU_THREADS) void k_interp(const SuInterpP q)
+// SL >= 0: the slab's sample arrays go through LDS: fp[rb][n_xp] | xp rows padded for su_count ([rb] of them, or one when
+// xp is shared)
+template <typename T, int SL, int WT> __global__ __launch_bounds__(SU_THREADS) void k_interp(const SuInterpP q)
 {
+    constexpr bool STAGE = SL >= 0;
     T *const lds = reinterpret_cast<T *>(spc_smem);
     const int64_t row0 = (int64_t)blockIdx.x * q.rb;
     const int nrow = (int)((q.n_rows - row0) < q.rb ? (q.n_rows - row0) : q.rb);
-    const int n_xp = q.n_xp, n_x = q.n_x, tid = threadIdx.x;
+    const int n_xp = q.n_xp, n_x = q.n_x, tid = threadIdx.x, stride = su_pad(q.p2);
     const T *const xg = (const T *)q.x, *const xpg = (const T *)q.xp, *const fpg = (const T *)q.fp;
     T *const out = (T *)q.out;
     T *const lfp = lds, *const lxp = lds + (size_t)q.rb * n_xp;
     if constexpr (STAGE) {
         su_stage<3>(lfp, nrow * n_xp, tid, su_slab<T>(q.fp, row0, q.pitch_fp, n_xp));
-        if (q.pitch_xp) su_stage<3>(lxp, nrow * n_xp, tid, su_slab<T>(q.xp, row0, q.pitch_xp, n_xp));
-        else su_stage<1>(lxp, n_xp, tid, [&](int e) { return ldg(xpg + e); });
+        if (q.pitch_xp) su_stage_rows<3>(lxp, nrow, n_xp, stride, tid, xpg + row0 * q.pitch_xp, (int)q.pitch_xp);
+        else su_stage_rows<2>(lxp, 1, n_xp, stride, tid, xpg, 0);
         __syncthreads();
     }
-    const bool flat_x = q.pitch_x == (int64_t)n_x, flat_o = q.pitch_out == (int64_t)n_x;
+    // addresses: the slab's (uniform) base + a 32-bit element offset r * pitch + i (the host keeps rb * pitch below 2^31)
+    const T *const xb = xg + row0 * q.pitch_x;
+    T *const ob = out + row0 * q.pitch_out;
+    const int px = (int)q.pitch_x, po = (int)q.pitch_out;
     const int cnt = nrow * n_x;
     int r = tid / n_x, i = tid - r * n_x;                     // (row, point) of this thread's first output; then stepped
     for (int e = tid; e < cnt; e += SU_THREADS) {
         const int64_t row = row0 + r;
-        const T xv = q.pitch_x ? (flat_x ? ldg(xg + row0 * n_x + e) : ldg(xg + row * q.pitch_x + i)) : ldg(xg + i);
+        const T xv = ldg(su_at(xb, r * px + i));
         T res;
         if constexpr (STAGE) {
-            const T *const xpr = q.pitch_xp ? lxp + (size_t)r * n_xp : lxp;
-            res = interp_at(bracket(xpr, n_xp, q.p2, xv), lfp + (size_t)r * n_xp);
+            const T *const xpr = q.pitch_xp ? lxp + (size_t)r * stride : lxp;
+            res = su_interp_at(bracket_pad<SL>(xpr, n_xp, q.p2, xv), lfp + (size_t)r * n_xp);
         } else {
             res = interp_at(bracket(xpg + row * q.pitch_xp, n_xp, q.p2, xv), fpg + row * q.pitch_fp);
         }
-        stg<WT>(flat_o ? out + row0 * n_x + e : out + row * q.pitch_out + i, res);
+        stg<WT>(su_at(ob, r * po + i), res);
         i += SU_THREADS;
         while (i >= n_x) { i -= n_x; ++r; }
     }
@@ -142,38 +238,45 @@ template <typename T> __device__ __forceinline__ int ss_left(const T *a, int n, 
 // ---- searchsorted --------------------------------------------------------------------------------------------------
 struct SuSearchP {
     int64_t n_rows, pitch_a, pitch_v, pitch_out;
-    int n_a, n_v, rb, right;
+    int n_a, n_v, rb, right, p2;
     const void *a, *v;
     int64_t *out;
 };
 
-template <typename T, bool STAGE, int WT> __global__ __launch_bounds__(SU_THREADS) void k_searchsorted(const SuSearchP q)
+template <typename T, int SL, int WT> __global__ __launch_bounds__(SU_THREADS) void k_searchsorted(const SuSearchP q)
 {
+    constexpr bool STAGE = SL >= 0;
     T *const lds = reinterpret_cast<T *>(spc_smem);
     const int64_t row0 = (int64_t)blockIdx.x * q.rb;
     const int nrow = (int)((q.n_rows - row0) < q.rb ? (q.n_rows - row0) : q.rb);
     const T *const ag = (const T *)q.a, *const vg = (const T *)q.v;
-    const int n_a = q.n_a, n_v = q.n_v, tid = threadIdx.x;
+    const int n_a = q.n_a, n_v = q.n_v, tid = threadIdx.x, stride = su_pad(q.p2);
     if constexpr (STAGE) {
-        if (q.pitch_a) su_stage<3>(lds, nrow * n_a, tid, su_slab<T>(q.a, row0, q.pitch_a, n_a));
-        else su_stage<1>(lds, n_a, tid, [&](int e) { return ldg(ag + e); });
+        if (q.pitch_a) su_stage_rows<3>(lds, nrow, n_a, stride, tid, ag + row0 * q.pitch_a, (int)q.pitch_a);
+        else su_stage_rows<2>(lds, 1, n_a, stride, tid, ag, 0);
         __syncthreads();
     }
-    const bool flat_v = q.pitch_v == (int64_t)n_v, flat_o = q.pitch_out == (int64_t)n_v;
+    const T *const vb = vg + row0 * q.pitch_v;
+    int64_t *const ob = q.out + row0 * q.pitch_out;
+    const int pv = (int)q.pitch_v, po = (int)q.pitch_out;
     const int cnt = nrow * n_v;
     int r = tid / n_v, i = tid - r * n_v;
     for (int e = tid; e < cnt; e += SU_THREADS) {
         const int64_t row = row0 + r;
-        const T key = q.pitch_v ? (flat_v ? ldg(vg + row0 * n_v + e) : ldg(vg + row * q.pitch_v + i)) : ldg(vg + i);
+        const T key = ldg(su_at(vb, r * pv + i));
         int idx;
         if constexpr (STAGE) {
-            const T *const ar = q.pitch_a ? lds + (size_t)r * n_a : lds;
-            idx = q.right ? ss_right(ar, n_a, key) : ss_left(ar, n_a, key);
+            // the insertion point of a sorted row = the number of entries in front of it: side='right' those with
+            // !(key < a[i]), side='left' those with a[i] < key, in numpy's NaN-last order (np_lt); a NaN key passes the
+            // NaN padding too, hence the clamp
+            const T *const ar = q.pitch_a ? lds + (size_t)r * stride : lds;
+            idx = q.right ? su_count<SL>(ar, q.p2, [&](T a) { return !np_lt(key, a); }) : su_count<SL>(ar, q.p2, [&](T a) { return np_lt(a, key); });
+            idx = idx < n_a ? idx : n_a;
         } else {
             const T *const ar = ag + row * q.pitch_a;
             idx = q.right ? ss_right(ar, n_a, key) : ss_left(ar, n_a, key);
         }
-        stg<WT>(flat_o ? q.out + row0 * n_v + e : q.out + row * q.pitch_out + i, (int64_t)idx);
+        stg<WT>(su_at(ob, r * po + i), (int64_t)idx);
         i += SU_THREADS;
         while (i >= n_v) { i -= n_v; ++r; }
     }
@@ -184,7 +287,7 @@ enum { SU_INTERP_C = 0, SU_INTERP_RHO = 1, SU_INTEGRAL = 2 };
 
 struct SuCoarseP {
     int64_t n_rows, pitch_Zh, pitch_zh, pitch_q, pitch_out;
-    int nG, nL, mode, rb;
+    int nG, nL, mode, rb, p2;          // p2: largest power of two <= nL - 1 (the rows z[1:] the cell scans count over)
     const void *Zh, *zh, *q, *rho;
     void *out;
 };
@@ -212,15 +315,17 @@ template <int PD, typename F> __device__ __forceinline__ auto su_npsum(const F &
 // LDS values in ndarray.sum() order (pairwise recursion unrolled to the depth PD the host derived from nL, as K4; PD = -1:
 // explicit stack).  The two edge pieces read q / w of the first and last cell from global memory (lines this workgroup has
 // just loaded).  STAGE = false (rows beyond the LDS): terms formed on the fly from global memory.
-template <typename T, int PD, bool STAGE, bool WEIGHTED, int WT> __global__ __launch_bounds__(SU_THREADS) void k_interp_c(const SuCoarseP p)
+template <typename T, int PD, int SL, bool WEIGHTED, int WT> __global__ __launch_bounds__(SU_THREADS) void k_interp_c(const SuCoarseP p)
 {
+    constexpr bool STAGE = SL >= 0;
     T *const lds = reinterpret_cast<T *>(spc_smem);
     const int64_t row0 = (int64_t)blockIdx.x * p.rb;
     const int nrow = (int)((p.n_rows - row0) < p.rb ? (p.n_rows - row0) : p.rb);
-    const int nL = p.nL, nG = p.nG, nc = nL - 1, tid = threadIdx.x;                    // nL points bound nc cells
+    const int nL = p.nL, nG = p.nG, nc = nL - 1, tid = threadIdx.x, zstride = su_pad(p.p2);     // nL points bound nc cells
     const T *const zg = (const T *)p.zh, *const qg = (const T *)p.q, *const wg = (const T *)p.rho;
-    // LDS: tn[rb][nc] | td[rb][nc] (WEIGHTED) | z[rb][nL] (or z[nL] when shared)
+    // LDS: tn[rb][nc] | td[rb][nc] (WEIGHTED) | z rows padded for su_count ([rb] of them, or one when zh is shared)
     T *const ltn = lds, *const ltd = lds + (size_t)p.rb * nc, *const lz = ltd + (WEIGHTED ? (size_t)p.rb * nc : 0);
+    const T *const qb = qg + row0 * p.pitch_q, *const wb = wg + row0 * p.pitch_q, *const zb = zg + row0 * p.pitch_zh;    // slab bases
     if constexpr (STAGE) {
         const int total = nrow * nc;
         int r0 = tid / nc, l0 = tid - r0 * nc;                 // (row, cell) of element e0; stepped, not divided
@@ -231,12 +336,11 @@ template <typename T, int PD, bool STAGE, bool WEIGHTED, int WT> __global__ __la
             for (int u = 0; u < 2; ++u) {
                 const bool in = e0 + u * SU_THREADS < total;
                 const int r = in ? rr : 0, l = in ? ll : 0;
-                const int64_t o = (row0 + r) * p.pitch_q + l;
-                const int64_t oz = p.pitch_zh ? (row0 + r) * p.pitch_zh + l : (int64_t)l;
-                qv[u] = ldg(qg + o);
-                wv[u] = WEIGHTED ? ldg(wg + o) : T(1);
-                z0[u] = ldg(zg + oz);
-                z1[u] = ldg(zg + oz + 1);
+                const int o = r * (int)p.pitch_q + l, oz = r * (int)p.pitch_zh + l;      // 32-bit offsets off the slab's bases
+                qv[u] = ldg(su_at(qb, o));
+                wv[u] = WEIGHTED ? ldg(su_at(wb, o)) : T(1);
+                z0[u] = ldg(su_at(zb, oz));
+                z1[u] = ldg(su_at(zb, oz + 1));
                 ll += SU_THREADS;
                 while (ll >= nc) { ll -= nc; ++rr; }
             }
@@ -251,17 +355,19 @@ template <typename T, int PD, bool STAGE, bool WEIGHTED, int WT> __global__ __la
                 }
             }
         }
-        if (p.pitch_zh) su_stage<2>(lz, nrow * nL, tid, su_slab<T>(p.zh, row0, p.pitch_zh, nL));
-        else su_stage<1>(lz, nL, tid, [&](int e) { return ldg(zg + e); });
+        if (p.pitch_zh) su_stage_rows<2>(lz, nrow, nL, zstride, tid, zb, (int)p.pitch_zh);
+        else su_stage_rows<2>(lz, 1, nL, zstride, tid, zg, 0);
         __syncthreads();
     }
+    const T *const Zb = (const T *)p.Zh + row0 * p.pitch_Zh;
+    T *const ob = (T *)p.out + row0 * p.pitch_out;
     const int cnt_out = nrow * nG;
     int r = tid / nG, k = tid - r * nG;
     for (int e = tid; e < cnt_out; e += SU_THREADS) {
         const int64_t row = row0 + r;
-        const T *const z = STAGE ? lz + (p.pitch_zh ? (size_t)r * nL : 0) : zg + row * p.pitch_zh;
-        const T *const Zh = (const T *)p.Zh + row * p.pitch_Zh;
-        const T top = ldg(Zh + k), bot = ldg(Zh + k + 1);
+        const T *const z = STAGE ? lz + (p.pitch_zh ? (size_t)r * zstride : 0) : zg + row * p.pitch_zh;
+        const int oZ = r * (int)p.pitch_Zh + k;
+        const T top = ldg(su_at(Zb, oZ)), bot = ldg(su_at(Zb, oZ + 1));
         T res = T(0);                                                                  // Q = zeros / RHO = zeros
         if (p.mode == SU_INTEGRAL || top < z[nL - 1]) {                                // sputils.py:187 / 195
             T a = bot, b = top;                                                        // integral(ZZ[i+1], ZZ[i], ...)
@@ -270,16 +376,24 @@ template <typename T, int PD, bool STAGE, bool WEIGHTED, int WT> __global__ __la
             } else {
                 T sign = T(1);
                 if (a > b) { sign = T(-1); const T t = a; a = b; b = t; }              // sputils.py:117-120
-                const int ia = scan_cell(z, nL, a);                                    // sputils.py:122-124
-                int ib = scan_cell(z, nL, b);                                          // sputils.py:125-127
+                // the scans `while z[i+1] < a: i += 1` (sputils.py:122-127) = the number of k >= 1 with z[k] < a; z[nL-1] < a
+                // is false (a <= z[nL-1] was checked), so the count stops at nL - 2 at the latest
+                int ia, ib;
+                if constexpr (STAGE) {
+                    ia = su_count<SL>(z + 1, p.p2, [&](T zk) { return zk < a; });
+                    ib = su_count<SL>(z + 1, p.p2, [&](T zk) { return zk < b; });
+                } else {
+                    ia = scan_cell(z, nL, a);
+                    ib = scan_cell(z, nL, b);
+                }
                 if (ib < ia) ib = ia;
                 const int cnt = ib - ia + 1;
                 const T da = a - z[ia], db = z[ib + 1] - b;
-                const T *const qr = qg + row * p.pitch_q, *const wr = wg + row * p.pitch_q;
-                const T qa = ldg(qr + ia), qb = ldg(qr + ib);
+                const T *const qr = qb + r * (int)p.pitch_q, *const wr = wb + r * (int)p.pitch_q;
+                const T qa = ldg(qr + ia), qe = ldg(qr + ib);
                 T num, den = T(1);
                 if constexpr (WEIGHTED) {
-                    const T wa = ldg(wr + ia), wb = ldg(wr + ib);
+                    const T wa = ldg(wr + ia), we = ldg(wr + ib);
                     Pair2<T> S;
                     if constexpr (STAGE) {
                         const T *const tn = ltn + (size_t)r * nc + ia, *const td = ltd + (size_t)r * nc + ia;
@@ -289,8 +403,8 @@ template <typename T, int PD, bool STAGE, bool WEIGHTED, int WT> __global__ __la
                             const T dz = z[ia + i + 1] - z[ia + i];
                             return Pair2<T>((wr[ia + i] * qr[ia + i]) * dz, wr[ia + i] * dz); }, cnt);
                     }
-                    num = (S.a - (wa * qa) * da) - (wb * qb) * db;                     // sputils.py:156-157
-                    den = (S.b - wa * da) - wb * db;                                   // sputils.py:160-161
+                    num = (S.a - (wa * qa) * da) - (we * qe) * db;                     // sputils.py:156-157
+                    den = (S.b - wa * da) - we * db;                                   // sputils.py:160-161
                     res = num / den * sign;                                            // sputils.py:162
                 } else {
                     T S;
@@ -300,13 +414,13 @@ template <typename T, int PD, bool STAGE, bool WEIGHTED, int WT> __global__ __la
                     } else {
                         S = su_npsum<PD>([&](int i) { return qr[ia + i] * (z[ia + i + 1] - z[ia + i]); }, cnt);
                     }
-                    num = (S - qa * da) - qb * db;                                     // sputils.py:149-152
+                    num = (S - qa * da) - qe * db;                                     // sputils.py:149-152
                     res = num * sign;
                 }
                 if (p.mode == SU_INTERP_RHO) res = res / (top - bot);                   // sputils.py:196
             }
         }
-        stg<WT>((T *)p.out + row * p.pitch_out + k, res);
+        stg<WT>(su_at(ob, r * (int)p.pitch_out + k), res);
         k += SU_THREADS;
         while (k >= nG) { k -= nG; ++r; }
     }

@@ -34,6 +34,41 @@ inline int su_rows(int64_t n_rows, int n_out, size_t lds_per_row, size_t lds_fix
     return rb;
 }
 
+// the kernels address a slab with 32-bit element offsets r * pitch + i (r < 64 rows): pitches stay below 2^24 elements
+inline bool su_pitch_ok(std::initializer_list<int64_t> pitches)
+{
+    for (int64_t p : pitches) if (p > ((int64_t)1 << 24)) return false;
+    return true;
+}
+
+// template argument SL of the staged kernels for a row whose power-of-two floor is p2: log2 p2 + 1 where that depth is
+// instantiated (rows of 64-127, 128-255, 256-511, 512-1023 entries: every level count of BASELINE.json's configs), else 0
+// (the same descent with the trip count at run time)
+inline int su_sl(int p2) { return p2 == 64 ? 7 : p2 == 128 ? 8 : p2 == 256 ? 9 : p2 == 512 ? 10 : 0; }
+
+// (the unrolled depths exist for double; the float twin runs the run-time descent)
+template <typename T, int WT> auto interp_kernel(int sl) -> void (*)(const SuInterpP)
+{
+    if constexpr (sizeof(T) == 8) {
+        if (sl == 7) return k_interp<T, 7, WT>;
+        if (sl == 8) return k_interp<T, 8, WT>;
+        if (sl == 9) return k_interp<T, 9, WT>;
+        if (sl == 10) return k_interp<T, 10, WT>;
+    }
+    return sl >= 0 ? k_interp<T, 0, WT> : k_interp<T, -1, WT>;
+}
+
+template <typename T, int WT> auto searchsorted_kernel(int sl) -> void (*)(const SuSearchP)
+{
+    if constexpr (sizeof(T) == 8) {
+        if (sl == 7) return k_searchsorted<T, 7, WT>;
+        if (sl == 8) return k_searchsorted<T, 8, WT>;
+        if (sl == 9) return k_searchsorted<T, 9, WT>;
+        if (sl == 10) return k_searchsorted<T, 10, WT>;
+    }
+    return sl >= 0 ? k_searchsorted<T, 0, WT> : k_searchsorted<T, -1, WT>;
+}
+
 template <typename T> int interp_impl(const spc_interp_args *a, void *stream)
 {
     if (!a) return fail(SPC_ERR_INVALID_ARGUMENT, "%sargs is NULL");
@@ -43,17 +78,20 @@ template <typename T> int interp_impl(const spc_interp_args *a, void *stream)
     REQUIRE(a->x, "x"); REQUIRE(a->xp, "xp"); REQUIRE(a->fp, "fp"); REQUIRE(a->out, "out");
     if ((a->pitch_x && a->pitch_x < a->n_x) || (a->pitch_xp && a->pitch_xp < a->n_xp) || a->pitch_fp < a->n_xp || a->pitch_out < a->n_x)
         return fail(SPC_ERR_INVALID_ARGUMENT, "%sinterp: a pitch is smaller than its row (only x and xp may be shared, pitch 0)");
+    if (!su_pitch_ok({a->pitch_x, a->pitch_xp, a->pitch_fp, a->pitch_out})) return fail(SPC_ERR_UNSUPPORTED, "%sinterp: a row pitch beyond 2^24 elements");
     SuInterpP q;
     q.n_rows = a->n_rows; q.pitch_x = a->pitch_x; q.pitch_xp = a->pitch_xp; q.pitch_fp = a->pitch_fp; q.pitch_out = a->pitch_out;
     q.n_x = a->n_x; q.n_xp = a->n_xp; q.p2 = floor_pow2(a->n_xp);
     int stage;
-    q.rb = su_rows(a->n_rows, a->n_x, (size_t)a->n_xp * (a->pitch_xp ? 2 : 1), a->pitch_xp ? 0 : a->n_xp, sizeof(T), &stage);
+    const size_t xrow = (size_t)su_pad(q.p2);            // a padded xp row in LDS
+    const size_t per_row = (size_t)a->n_xp + (a->pitch_xp ? xrow : 0), fixed = a->pitch_xp ? 0 : xrow;
+    q.rb = su_rows(a->n_rows, a->n_x, per_row, fixed, sizeof(T), &stage);
     if ((a->n_rows + q.rb - 1) / q.rb > 0x7fffffff) return fail(SPC_ERR_UNSUPPORTED, "%sinterp: too many rows for one launch");
     q.x = a->x; q.xp = a->xp; q.fp = a->fp; q.out = a->out;
-    const size_t smem = stage ? ((size_t)a->n_xp * (a->pitch_xp ? 2 : 1) * q.rb + (a->pitch_xp ? 0 : a->n_xp)) * sizeof(T) : 0;
+    const size_t smem = stage ? (per_row * q.rb + fixed) * sizeof(T) : 0;
     const int64_t wr = a->n_rows * (int64_t)a->n_x * (int64_t)sizeof(T);
-    void (*kern)(const SuInterpP) = stage ? SU_PICK_WT((k_interp<T, true, 1>), (k_interp<T, true, 0>), wr)
-                                          : SU_PICK_WT((k_interp<T, false, 1>), (k_interp<T, false, 0>), wr);
+    const int sl = stage ? su_sl(q.p2) : -1;
+    void (*kern)(const SuInterpP) = small_batch(wr) ? interp_kernel<T, 1>(sl) : interp_kernel<T, 0>(sl);
     hipLaunchKernelGGL(kern, dim3((unsigned)((a->n_rows + q.rb - 1) / q.rb)), dim3(SU_THREADS), smem, (hipStream_t)stream, q);
     return launch_status("k_interp");
 }
@@ -67,31 +105,42 @@ template <typename T> int searchsorted_impl(const spc_searchsorted_args *a, void
     if (a->n_a) REQUIRE(a->a, "a");
     if ((a->pitch_a && a->pitch_a < a->n_a) || (a->pitch_v && a->pitch_v < a->n_v) || a->pitch_out < a->n_v)
         return fail(SPC_ERR_INVALID_ARGUMENT, "%ssearchsorted: a pitch is smaller than its row (only a and v may be shared, pitch 0)");
+    if (!su_pitch_ok({a->pitch_a, a->pitch_v, a->pitch_out})) return fail(SPC_ERR_UNSUPPORTED, "%ssearchsorted: a row pitch beyond 2^24 elements");
     SuSearchP q;
     q.n_rows = a->n_rows; q.pitch_a = a->pitch_a; q.pitch_v = a->pitch_v; q.pitch_out = a->pitch_out;
-    q.n_a = a->n_a; q.n_v = a->n_v; q.right = a->side_right != 0;
+    q.n_a = a->n_a; q.n_v = a->n_v; q.right = a->side_right != 0; q.p2 = floor_pow2(a->n_a);
     int stage;
-    q.rb = su_rows(a->n_rows, a->n_v, a->pitch_a ? a->n_a : 0, a->pitch_a ? 0 : a->n_a, sizeof(T), &stage);
+    const size_t arow = (size_t)su_pad(q.p2);
+    q.rb = su_rows(a->n_rows, a->n_v, a->pitch_a ? arow : 0, a->pitch_a ? 0 : arow, sizeof(T), &stage);
     if ((a->n_rows + q.rb - 1) / q.rb > 0x7fffffff) return fail(SPC_ERR_UNSUPPORTED, "%ssearchsorted: too many rows for one launch");
     q.a = a->a; q.v = a->v; q.out = a->out;
-    const size_t smem = stage ? ((size_t)(a->pitch_a ? a->n_a : 0) * q.rb + (a->pitch_a ? 0 : a->n_a)) * sizeof(T) : 0;
+    const size_t smem = stage ? ((a->pitch_a ? arow : 0) * q.rb + (a->pitch_a ? 0 : arow)) * sizeof(T) : 0;
     const int64_t wr = a->n_rows * (int64_t)a->n_v * 8;
-    void (*kern)(const SuSearchP) = stage ? SU_PICK_WT((k_searchsorted<T, true, 1>), (k_searchsorted<T, true, 0>), wr)
-                                          : SU_PICK_WT((k_searchsorted<T, false, 1>), (k_searchsorted<T, false, 0>), wr);
+    const int sl = stage ? su_sl(q.p2) : -1;
+    void (*kern)(const SuSearchP) = small_batch(wr) ? searchsorted_kernel<T, 1>(sl) : searchsorted_kernel<T, 0>(sl);
     hipLaunchKernelGGL(kern, dim3((unsigned)((a->n_rows + q.rb - 1) / q.rb)), dim3(SU_THREADS), smem, (hipStream_t)stream, q);
     return launch_status("k_searchsorted");
 }
 
-// the instantiation of k_interp_c for (PD, STAGE, WEIGHTED, WT); the unrolled depths exist for the staged double kernel
-template <typename T, bool STAGE, bool W, int WT> auto interp_c_kernel(int pd) -> void (*)(const SuCoarseP)
+// the instantiation of k_interp_c for (PD, SL, WEIGHTED, WT); the unrolled sum depths exist for the staged double kernel
+template <typename T, int SL, bool W, int WT> auto interp_c_kernel(int pd) -> void (*)(const SuCoarseP)
 {
-    if constexpr (sizeof(T) == 8 && STAGE) {
-        if (pd == 1) return k_interp_c<T, 1, STAGE, W, WT>;
-        if (pd == 2) return k_interp_c<T, 2, STAGE, W, WT>;
-        if (pd == 3) return k_interp_c<T, 3, STAGE, W, WT>;
+    if constexpr (sizeof(T) == 8 && SL >= 0) {
+        if (pd == 1) return k_interp_c<T, 1, SL, W, WT>;
+        if (pd == 2) return k_interp_c<T, 2, SL, W, WT>;
+        if (pd == 3) return k_interp_c<T, 3, SL, W, WT>;
     }
     (void)pd;
-    return k_interp_c<T, -1, STAGE, W, WT>;
+    return k_interp_c<T, -1, SL, W, WT>;
+}
+
+template <typename T, bool W, int WT> auto interp_c_kernel_sl(int sl, int pd) -> void (*)(const SuCoarseP)
+{
+    if constexpr (sizeof(T) == 8) {              // nL = 160 -> rows z[1:] of 159 entries: SL 8; nL = 512: SL 9
+        if (sl == 8) return interp_c_kernel<T, 8, W, WT>(pd);
+        if (sl == 9) return interp_c_kernel<T, 9, W, WT>(pd);
+    }
+    return sl >= 0 ? interp_c_kernel<T, 0, W, WT>(pd) : interp_c_kernel<T, -1, W, WT>(pd);
 }
 
 template <typename T> int interp_c_impl(const spc_interp_c_args *a, void *stream)
@@ -106,25 +155,26 @@ template <typename T> int interp_c_impl(const spc_interp_c_args *a, void *stream
     if (a->n_rows > 0x7fffffff) return fail(SPC_ERR_UNSUPPORTED, "%sinterp_c: more than 2^31-1 rows");
     if (a->pitch_Zh < a->nG + 1 || (a->pitch_zh && a->pitch_zh < a->nL) || a->pitch_q < a->nL - 1 || a->pitch_out < a->nG)
         return fail(SPC_ERR_INVALID_ARGUMENT, "%sinterp_c: a pitch is smaller than its row (only zh may be shared, pitch 0)");
+    if (!su_pitch_ok({a->pitch_Zh, a->pitch_zh, a->pitch_q, a->pitch_out})) return fail(SPC_ERR_UNSUPPORTED, "%sinterp_c: a row pitch beyond 2^24 elements");
     SuCoarseP q;
     q.n_rows = a->n_rows; q.pitch_Zh = a->pitch_Zh; q.pitch_zh = a->pitch_zh; q.pitch_q = a->pitch_q; q.pitch_out = a->pitch_out;
     q.nG = a->nG; q.nL = a->nL; q.mode = a->mode;
     q.Zh = a->Zh; q.zh = a->zh; q.q = a->q; q.rho = a->mode == SU_INTERP_RHO ? nullptr : a->rho; q.out = a->out;
     const bool weighted = q.rho != nullptr;
-    // LDS per row: the cell terms tn (and td with weights) [nL - 1] + the row's grid [nL] unless it is shared
-    const size_t per_row = (size_t)(a->nL - 1) * (weighted ? 2 : 1) + (a->pitch_zh ? a->nL : 0);
+    q.p2 = floor_pow2(a->nL - 1);
+    // LDS per row: the cell terms tn (and td with weights) [nL - 1] + the row's padded grid unless the grid is shared
+    const size_t zrow = (size_t)su_pad(q.p2);
+    const size_t per_row = (size_t)(a->nL - 1) * (weighted ? 2 : 1) + (a->pitch_zh ? zrow : 0), fixed = a->pitch_zh ? 0 : zrow;
     int stage;
-    q.rb = su_rows(a->n_rows, a->nG, per_row, a->pitch_zh ? 0 : a->nL, sizeof(T), &stage);
-    const size_t smem = stage ? (per_row * q.rb + (a->pitch_zh ? 0 : a->nL)) * sizeof(T) : 0;
+    q.rb = su_rows(a->n_rows, a->nG, per_row, fixed, sizeof(T), &stage);
+    const size_t smem = stage ? (per_row * q.rb + fixed) * sizeof(T) : 0;
     // numpy's pairwise recursion unrolled to the depth a layer of <= nL - 1 cells needs (cons_depth, as K4); the float twin
     // and grids of more than 1024 points keep the explicit stack
     const int pd = sizeof(T) == 8 ? cons_depth(a->nL) : -1;
     const bool wt = small_batch(a->n_rows * (int64_t)a->nG * (int64_t)sizeof(T)) != 0;
-    void (*kern)(const SuCoarseP);
-    if (stage) kern = weighted ? (wt ? interp_c_kernel<T, true, true, 1>(pd) : interp_c_kernel<T, true, true, 0>(pd))
-                               : (wt ? interp_c_kernel<T, true, false, 1>(pd) : interp_c_kernel<T, true, false, 0>(pd));
-    else kern = weighted ? (wt ? interp_c_kernel<T, false, true, 1>(pd) : interp_c_kernel<T, false, true, 0>(pd))
-                         : (wt ? interp_c_kernel<T, false, false, 1>(pd) : interp_c_kernel<T, false, false, 0>(pd));
+    const int sl = stage ? su_sl(q.p2) : -1;
+    void (*kern)(const SuCoarseP) = weighted ? (wt ? interp_c_kernel_sl<T, true, 1>(sl, pd) : interp_c_kernel_sl<T, true, 0>(sl, pd))
+                                             : (wt ? interp_c_kernel_sl<T, false, 1>(sl, pd) : interp_c_kernel_sl<T, false, 0>(sl, pd));
     hipLaunchKernelGGL(kern, dim3((unsigned)((a->n_rows + q.rb - 1) / q.rb)), dim3(SU_THREADS), smem, (hipStream_t)stream, q);
     return launch_status("k_interp_c");
 }

@@ -184,6 +184,29 @@ def verify(fplan, bplan, ref_f, ref_b, n_ref, factor, dt):
     return (not bad), dict(det, columns_checked=int(n_ref), bit_exact=BIT_EXACT, failures=bad)
 
 
+def pow_ulp_histogram(eng, pf):
+    """iexner(Pf) = (Pf / pref0) ** (-rd / cp) (sputils.py:33-34), the one transcendental of the path, three ways: the HIP
+    kernel's own spc_pow, NumPy's `**` (its SIMD pow: what the reference runs) and glibc's pow (what the plain-C oracle
+    runs).  Distance in units in the last place, as a histogram.  The two CPU results differ from EACH OTHER on a few
+    percent of the points, so bit-parity of thl is not defined by the reference itself; the kernel's pow is within
+    0.56 ulp of the exact value (tools/csrc/pow_accuracy.c), i.e. at most 1 ulp from either."""
+    import math
+    import numpy
+    import torch
+    x = numpy.ascontiguousarray(pf, dtype=numpy.float64)
+    got = eng.exner(torch.from_numpy(x).to(eng.device), inverse=True).cpu().numpy()
+    y = (-287.04) / 1004.
+    np_pow = (x / 1e5) ** y
+    libm = numpy.fromiter((math.pow(v, y) for v in (x / 1e5).ravel()), dtype=numpy.float64, count=x.size).reshape(x.shape)
+
+    def hist(a, b):
+        d = numpy.abs(a.view(numpy.int64) - b.view(numpy.int64))
+        return {"0": float((d == 0).mean()), "1": float((d == 1).mean()), "2": float((d == 2).mean()), ">2": float((d > 2).mean()),
+                "max": int(d.max())}
+    return {"points": int(x.size), "hip_vs_numpy_pow": hist(got, np_pow), "hip_vs_glibc_pow": hist(got, libm),
+            "numpy_pow_vs_glibc_pow": hist(np_pow, libm), "unit": "fraction of points at that distance (ulp)"}
+
+
 def sample_rows(n, m=4096):
     """row numbers of a check sample of (at most) m rows of an n-row block: its first and last m/3 rows and m/3 rows
     spread evenly over the rest -- always including row 0 and row n - 1"""
@@ -993,6 +1016,10 @@ def main():
         out["cpu_baseline"] = base
         # batch 0 was last written by the per-kernel loops above with the same inputs: check it
         ok, detail = verify(wl.fplans[0], wl.bplans[0], ref_f, ref_b, m, factor, dt_gcm)
+        try:
+            detail["iexner_ulp_distance"] = pow_ulp_histogram(eng, gs["Pfull"][:2048])
+        except Exception as e:                           # a reported extra
+            detail["iexner_ulp_distance"] = {"error": repr(e)}
         out["verified"], out["verified_detail"] = ok, detail
         workers = min(16, os.cpu_count() or 1)
         if workers > 1 and not args.no_cpu_multicore:

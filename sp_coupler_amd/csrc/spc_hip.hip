@@ -77,15 +77,13 @@ __device__ __forceinline__ double spc_pow(double x, double y) { return x * y; }
 #elif defined(SPC_OCML_POW)
 __device__ __forceinline__ double spc_pow(double x, double y) { return pow(x, y); }
 #else
-// x**y for the two exponents of this path, y = -+rd/cp (sputils.py:28-34), |y| <= 1, x = p/pref0 in (0, ~1.1].
-// ocml's general pow() is 245 instructions; with the exponent's size known the same accuracy class needs ~60:
-//   log x = e ln2 + log m (m in [sqrt 1/2, sqrt 2), atanh series in f = (m-1)/(m+1)), carried as hi + lo so that the
-//   product y log x keeps ~2^-57 relative accuracy, then exp of the reduced argument by its Taylor polynomial.
-// Measured on the host with the same IEEE operations against a long-double reference (2e7 points each exponent,
-// 1e-6 <= x <= 1.2 and the full exponent range): worst error 1.20 ulp, > 1 ulp in 1.4e-5 of the points (libm: 0.51 ulp).
+// x**y for the two exponents of this path, y = -+rd/cp (sputils.py:28-34), |y| <= 1: spc_pow.h (one source for this file and
+// for the host accuracy sweep tools/csrc/pow_accuracy.c; round 4: <= 0.56 ulp against an 80-bit reference, was 1.2).
 // Arguments outside (0, inf) get C99 pow()'s special values for a non-integer exponent, inline (0 -> inf or 0, inf -> 0 or
 // inf, negative -> NaN, -inf like +inf, NaN -> NaN); subnormal x goes through the same code (frexp normalises it).  No
 // call: an out-of-line ocml pow() made every K1 wave reserve ITS 100 registers (4 waves per SIMD instead of 6).
+#define SPC_POW_FN __device__ __forceinline__
+#include "spc_pow.h"
 __device__ __forceinline__ double spc_pow(double x, double y)
 {
     if (!(x > 0.0 && x <= 1.7976931348623157e308)) {
@@ -95,32 +93,7 @@ __device__ __forceinline__ double spc_pow(double x, double y)
         if (x == big || x == -big) return y < 0.0 ? 0.0 : big;                     // +-inf (not an odd integer y)
         return __builtin_nan("");                                                  // negative finite x, non-integer y
     }
-    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10, LOG2E = 1.44269504088896338700e+00;
-    int e;
-    double m = frexp(x, &e);                                         // [0.5, 1)
-    if (m < 0.70710678118654752440) { m *= 2.0; e -= 1; }            // [sqrt 1/2, sqrt 2)
-    const double f = (m - 1.0) / (m + 1.0), s = f * f;
-    double P = 2.0 / 21.0;
-    P = __builtin_fma(P, s, 2.0 / 19.0); P = __builtin_fma(P, s, 2.0 / 17.0); P = __builtin_fma(P, s, 2.0 / 15.0);
-    P = __builtin_fma(P, s, 2.0 / 13.0); P = __builtin_fma(P, s, 2.0 / 11.0); P = __builtin_fma(P, s, 2.0 / 9.0);
-    P = __builtin_fma(P, s, 2.0 / 7.0); P = __builtin_fma(P, s, 2.0 / 5.0); P = __builtin_fma(P, s, 2.0 / 3.0);
-    const double logm = __builtin_fma(f * s, P, 2.0 * f);
-    const double ed = (double)e;
-    const double L_hi = ed * LN2_HI;                                 // exact: LN2_HI has 32 significant bits
-    const double L_lo = __builtin_fma(ed, LN2_LO, logm);
-    const double t_hi = y * L_hi;
-    const double t_lo = __builtin_fma(y, L_lo, __builtin_fma(y, L_hi, -t_hi));
-    const double t = t_hi + t_lo, tl = t_lo - (t - t_hi);
-    const double n = rint(t * LOG2E);
-    double r = __builtin_fma(-n, LN2_HI, t);
-    r = __builtin_fma(-n, LN2_LO, r);
-    r += tl;
-    double q = 1.0 / 6227020800.0;
-    q = __builtin_fma(q, r, 1.0 / 479001600.0); q = __builtin_fma(q, r, 1.0 / 39916800.0); q = __builtin_fma(q, r, 1.0 / 3628800.0);
-    q = __builtin_fma(q, r, 1.0 / 362880.0); q = __builtin_fma(q, r, 1.0 / 40320.0); q = __builtin_fma(q, r, 1.0 / 5040.0);
-    q = __builtin_fma(q, r, 1.0 / 720.0); q = __builtin_fma(q, r, 1.0 / 120.0); q = __builtin_fma(q, r, 1.0 / 24.0);
-    q = __builtin_fma(q, r, 1.0 / 6.0); q = __builtin_fma(q, r, 0.5); q = __builtin_fma(q, r, 1.0); q = __builtin_fma(q, r, 1.0);
-    return ldexp(q, (int)n);
+    return spc_pow_pos(x, y);
 }
 #endif
 __device__ __forceinline__ float spc_pow(float x, float y) { return powf(x, y); }
@@ -665,6 +638,7 @@ template <typename T, int NG, int NL, int WT, int BLK = BLOCK, bool PRE = true> 
     T *const lds = reinterpret_cast<T *>(spc_smem);
     T *const lh = lds + (size_t)cb * per_col;
     const int n1 = ncol * nG;
+    STAMP(0);
 
     // Loads are issued in the order the data is NEEDED (memory returns roughly in issue order and
     // s_waitcnt vmcnt counts in issue order): first this thread's first staging element of every LES array
@@ -699,6 +673,7 @@ template <typename T, int NG, int NL, int WT, int BLK = BLOCK, bool PRE = true> 
         const int64_t cg = (col0 + c) * pitchG;
         pre = load_gcm(p, cg + k, cg + (nG - 1 - k));
     }
+    STAMP(1);
 
     for (int e = tid; e < n2; e += BLK) {
         const int c = e / nL, l = e - c * nL;
@@ -719,7 +694,9 @@ template <typename T, int NG, int NL, int WT, int BLK = BLOCK, bool PRE = true> 
         const int64_t col = col0 + c;
         lds[(size_t)c * per_col + 6 * nL + k] = (e == tid) ? zf0 : load_zf(col, col * pitchG + k);
     }
+    STAMP(2);
     __syncthreads();
+    STAMP(3);
 
     for (int e = tid; e < n1; e += BLK) {
         const int c = e / nG, k = e - c * nG;
@@ -776,6 +753,8 @@ template <typename T, int NG, int NL, int WT, int BLK = BLOCK, bool PRE = true> 
         stg<WT>(&p.f_A[g], f_A);
         if (p.start_index && k == 0) p.start_index[col] = start_index;
     }
+    STAMP(4);
+    STAMP(5);
 }
 
 #include "spc_vnudge.hpp"

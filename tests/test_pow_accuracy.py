@@ -1,0 +1,21 @@
+"""CPU: accuracy of the kernels' own pow (sp_coupler_amd/csrc/spc_pow.h, x ** (-+rd/cp) of sputils.exner / iexner,
+splib/sputils.py:28-34) -- the device's source compiled for the host with the same IEEE operations (fma, no contraction)
+and compared with powl in 80-bit arithmetic (tools/csrc/pow_accuracy.c).  Round-3 verdict, item 6: <= 0.6 ulp."""
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_spc_pow_is_within_0_6_ulp_of_the_exact_power(tmp_path):
+    exe = str(tmp_path / "pow_accuracy")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-mfma", "-o", exe, os.path.join(ROOT, "tools", "csrc", "pow_accuracy.c"), "-lm"],
+                   check=True)
+    out = subprocess.run([exe, "2000000"], check=True, capture_output=True, text=True).stdout
+    rows = [ln for ln in out.splitlines() if ln.startswith("spc_pow")]
+    assert len(rows) == 6, out
+    for ln in rows:
+        worst = float(re.search(r"worst ([0-9.]+) ulp", ln).group(1))
+        above = float(re.search(r"> 0.6 ulp ([0-9.e+-]+)", ln).group(1))
+        assert worst <= 0.6 and above == 0.0, ln

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Diagnostic: where K1's time goes at small batches. Builds a -DSPC_STAMPS variant of the library
-(never shipped), runs K1 once warm, prints per-phase medians from in-kernel 100 MHz wall-clock stamps."""
+"""Diagnostic: where K1's / K3's time goes at small batches. Builds a -DSPC_STAMPS variant of the library
+(never shipped), runs the kernel once warm, prints per-phase medians from in-kernel 100 MHz wall-clock stamps.
+usage: tools/stamps.py [n_cols] [cols_per_block] [k1|k3]      (STAMP_MODE=2: entry / end only, no intermediate drains)"""
 import ctypes
 import os
 import subprocess
@@ -22,6 +23,7 @@ from sp_coupler_amd.engine import Engine  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 cb = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+which = sys.argv[3] if len(sys.argv) > 3 else "k1"
 eng = Engine("cuda:0")
 eng.lib.spc_debug_set_stamps.argtypes = [ctypes.c_void_p]
 plans = []
@@ -31,8 +33,11 @@ for r in range(ROT):
     prof = {k: v for k, v in prof.items() if k not in ("Rain", "rain_last")}      # lean hot path, as bench.py
     g = {k: torch.from_numpy(v).cuda() for k, v in gcm.items()}
     p = {k: torch.from_numpy(v).cuda() for k, v in prof.items()}
-    plans.append(eng.plan_forward(g, torch.from_numpy(zf).cuda(), p, 1.0, 900.0, zh=torch.from_numpy(zh).cuda(),
-                                  want_heights=False, cols_per_block=cb))
+    if which == "k3":
+        plans.append(eng.plan_backward(g, torch.from_numpy(zf).cuda(), p, 1.0, 900.0, Zf=None, want_start_index=False, cols_per_block=cb))
+    else:
+        plans.append(eng.plan_forward(g, torch.from_numpy(zf).cuda(), p, 1.0, 900.0, zh=torch.from_numpy(zh).cuda(),
+                                      want_heights=False, cols_per_block=cb))
 nblk = (n + max(cb, 1) - 1) // max(cb, 1) if cb else n
 stamps = torch.zeros(n * 8, dtype=torch.int64, device="cuda")
 import time  # noqa: E402
@@ -49,6 +54,10 @@ st = st[st[:, 0] > 0][:, :6].astype(numpy.float64) * 10.0   # ns
 t0 = st[:, 0].min()
 names = ["entry", "prologue loads landed", "phase1 done (pow, LDS)", "barrier passed",
          "phase2+idx done (stores landed)", "end"]
+if which == "k3":
+    names = ["entry", "prologue loads landed (LES slab, Zf, GCM inputs)", "staged in LDS", "barrier passed",
+             "searches, 7 interpolations, tendencies; stores landed", "end"]
+print(plans[0].describe())
 print("blocks stamped:", len(st), " kernel span (first entry -> last end): %.2f us" % ((st[:, 5].max() - t0) / 1e3))
 print("entry spread: %.2f us" % ((st[:, 0].max() - t0) / 1e3))
 if mode == "2":

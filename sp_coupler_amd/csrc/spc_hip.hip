@@ -1008,7 +1008,9 @@ int env_int(const char *name, int dflt)
 int small_block(const spc_dims *d, int items_per_col)
 {
     if (d->cols_per_block != 0 || items_per_col > BLOCK || d->n_cols <= 256 || d->n_cols > 1024) return 0;
-    if (!env_int("SPC_SMALL_BLOCK", 1)) return 0;
+    const int sb = env_int("SPC_SMALL_BLOCK", 1);                    // 0: off; 2 / 4: that many columns per workgroup (A/B)
+    if (!sb) return 0;
+    if (sb == 2 || sb == 4) return sb;
     return d->n_cols <= 512 ? 2 : 4;
 }
 

@@ -61,6 +61,7 @@ template <typename T, int NG = 0, int NL = 0, int PD = -1> __global__ __launch_b
     T *const lzh = lds + (size_t)cb * per_col;                       // zh
     T *const ltop = lzh + (d.shared_grid ? nL : (size_t)cb * nL);    // zf[nL-1] per column
     const int n1 = ncol * nG;
+    STAMP(0);
 
     // ---- stage the LES slab, the LES half levels and the GCM heights --------------------------------------------
     for (int e = tid; e < ncol * nL; e += BLOCK) {
@@ -91,6 +92,7 @@ template <typename T, int NG = 0, int NL = 0, int PD = -1> __global__ __launch_b
         }
     }
     __syncthreads();
+    STAMP(1);
 
     // ---- per GCM level, once: which LES cells the layer [Zh[k+1], Zh[k]] covers (the scans of integral(), sputils.py:
     //      113-127).  ia < 0 encodes the two special outcomes: -1 layer above the LES top (Q stays 0, sputils.py:187),
@@ -124,6 +126,7 @@ template <typename T, int NG = 0, int NL = 0, int PD = -1> __global__ __launch_b
         cell[k] = (ia & 0xffff) | (ib * 65536);       // |ia|, |ib| < 2^15: an LES column of that height would not fit the LDS
     }
     __syncthreads();
+    STAMP(2);
 
     // ---- layer means: thread = (column, GCM level, field); lane&7 = field, 7 = the weight sum -------------------
     for (int e = tid; e < n1 * 8; e += BLOCK) {
@@ -167,6 +170,7 @@ template <typename T, int NG = 0, int NL = 0, int PD = -1> __global__ __launch_b
         if (f < 7) s[o_X + (size_t)f * nG + k] = X;
     }
     __syncthreads();
+    STAMP(3);
 
     // ---- tendencies: flat over the [ncol x nG] slab, as K3 (spcpl.py:498, 518-533) -----------------------------
     for (int e = tid; e < n1; e += BLOCK) {
@@ -198,4 +202,6 @@ template <typename T, int NG = 0, int NL = 0, int PD = -1> __global__ __launch_b
         p.f_A[g] = f_A;
         if (p.start_index && k == 0) p.start_index[col] = start_index;
     }
+    STAMP(4);
+    STAMP(5);
 }

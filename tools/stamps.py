@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: where K1's / K3's time goes at small batches. Builds a -DSPC_STAMPS variant of the library
 (never shipped), runs the kernel once warm, prints per-phase medians from in-kernel 100 MHz wall-clock stamps.
-usage: tools/stamps.py [n_cols] [cols_per_block] [k1|k3]      (STAMP_MODE=2: entry / end only, no intermediate drains)"""
+usage: tools/stamps.py [n_cols] [cols_per_block] [k1|k3|k4]      (STAMP_MODE=2: entry / end only, no intermediate drains)"""
 import ctypes
 import os
 import subprocess
@@ -33,8 +33,9 @@ for r in range(ROT):
     prof = {k: v for k, v in prof.items() if k not in ("Rain", "rain_last")}      # lean hot path, as bench.py
     g = {k: torch.from_numpy(v).cuda() for k, v in gcm.items()}
     p = {k: torch.from_numpy(v).cuda() for k, v in prof.items()}
-    if which == "k3":
-        plans.append(eng.plan_backward(g, torch.from_numpy(zf).cuda(), p, 1.0, 900.0, Zf=None, want_start_index=False, cols_per_block=cb))
+    if which in ("k3", "k4"):
+        plans.append(eng.plan_backward(g, torch.from_numpy(zf).cuda(), p, 1.0, 900.0, Zf=None, want_start_index=False, cols_per_block=cb,
+                                       conservative=(which == "k4"), zh=torch.from_numpy(zh).cuda()))
     else:
         plans.append(eng.plan_forward(g, torch.from_numpy(zf).cuda(), p, 1.0, 900.0, zh=torch.from_numpy(zh).cuda(),
                                       want_heights=False, cols_per_block=cb))
@@ -57,6 +58,9 @@ names = ["entry", "prologue loads landed", "phase1 done (pow, LDS)", "barrier pa
 if which == "k3":
     names = ["entry", "prologue loads landed (LES slab, Zf, GCM inputs)", "staged in LDS", "barrier passed",
              "searches, 7 interpolations, tendencies; stores landed", "end"]
+if which == "k4":
+    names = ["entry", "LES slab, heights staged; barrier", "cell ranges (two scans per level); barrier", "layer sums (8 lanes per level); barrier",
+             "tendencies; stores landed", "end"]
 print(plans[0].describe())
 print("blocks stamped:", len(st), " kernel span (first entry -> last end): %.2f us" % ((st[:, 5].max() - t0) / 1e3))
 print("entry spread: %.2f us" % ((st[:, 0].max() - t0) / 1e3))

@@ -778,6 +778,32 @@ template <typename T> __device__ __forceinline__ int scan_cell(const T *z, int n
     return lo - 1;
 }
 
+// ---- searches on LDS rows: fixed trip count, no bounds check -------------------------------------------------------
+// The three searches of this file -- numpy.interp's bracket (count of xp[i] <= x), numpy.searchsorted (count of entries
+// in front of the insertion point) and integral()'s cell scan (count of z[k] < a) -- are prefix counts over an ascending
+// row.  A staged row is PADDED WITH NaN up to 2 p2 entries (p2 = the largest power of two <= its length): the greedy
+// power-of-two descent of upper_count() then needs no `t <= n` test, because no predicate used here advances on a NaN
+// (searchsorted with a NaN key is the one exception and clamps), and with the trip count a template argument (SL =
+// log2 p2 + 1) every probe is one ds_read with an immediate offset + compare + select: 3 VALU instructions per step
+// instead of 8-12 (round 4: the first K7 generation was bound by VALU issue, 100-150 instructions per output,
+// profiles/r04_k7_counters.log).  SL = 0: the same descent with p2 at run time; SL = -1: nothing staged (rows beyond
+// the LDS), the operators fall back to the loops on global memory.
+__host__ __device__ inline int su_pad(int p2) { return 2 * p2 + 2; }      // entries of a padded row (+2: rows off each other's banks)
+
+template <int SL, typename T, typename Pred> __device__ __forceinline__ int su_count(const T *row, int p2, const Pred &adv)
+{
+    int pos = 0;
+    if constexpr (SL > 0) {
+#pragma unroll
+        for (int s = 1 << (SL - 1); s > 0; s >>= 1)
+            if (adv(row[pos + s - 1])) pos += s;
+    } else {
+        for (int s = p2; s > 0; s >>= 1)
+            if (adv(row[pos + s - 1])) pos += s;
+    }
+    return pos;
+}
+
 #include "spc_k4.hpp"
 #include "spc_sputils.hpp"
 
@@ -867,7 +893,9 @@ int validate(const spc_dims *d)
     return SPC_OK;
 }
 
-// LDS elements per column / per block for each pass (pass 0 fwd, 1 bwd, 2 idx, 3 diag)
+int geometry_id(const spc_dims *d);
+
+// LDS elements per column / per block for each pass (pass 0 fwd, 1 bwd, 2 idx, 3 diag, 4 conservative bwd)
 void lds_elems(const spc_dims *d, int pass, bool with_idx, size_t *per_col, size_t *fixed, size_t esize = 8)
 {
     const size_t nG = d->nG, nL = d->nL;
@@ -875,7 +903,14 @@ void lds_elems(const spc_dims *d, int pass, bool with_idx, size_t *per_col, size
     switch (pass) {
     case 0: *per_col = 6 * nG + ((with_idx && !sh) ? nL : 0); *fixed = (with_idx && sh) ? nL : 0; break;
     case 1: *per_col = 6 * nL + nG + (sh ? 0 : nL); *fixed = sh ? nL : 0; break;
-    case 4: *per_col = 7 * (nL + 1) + 8 * nG + 2 + (nG * 4 + esize - 1) / esize + 1 + (sh ? 0 : nL); *fixed = sh ? nL : 0; break;   // spc_k4.hpp; + zf[nL-1] per column
+    case 4:
+        if (geometry_id(d) != 0) {   // k_backward_cons3: A[8][nL+1] | Zh[nG+1] | cell[nG] | start index; zh rows NaN-padded; dz when shared
+            const size_t zrow = (size_t)su_pad(floor_pow2((int)nL - 1));
+            *per_col = 8 * (nL + 1) + (nG + 1) + (nG * 4 + esize - 1) / esize + 1 + (sh ? 0 : zrow);
+            *fixed = sh ? zrow + (nL - 1) : 0;
+            break;
+        }
+        *per_col = 7 * (nL + 1) + 8 * nG + 2 + (nG * 4 + esize - 1) / esize + 1 + (sh ? 0 : nL); *fixed = sh ? nL : 0; break;   // k_backward_cons2; + zf[nL-1] per column
     case 2: *per_col = sh ? 0 : nL; *fixed = sh ? nL : 0; break;
     default: *per_col = 2 * nG; *fixed = 0; break;
     }
@@ -1179,15 +1214,34 @@ template <typename T> KBwd<T> bwd_kernel(int geo, int wt, int blk, int pre)
 
 // K4 of a geometry; run-time geometry (geo 0): numpy's pairwise recursion unrolled to the depth nL needs (spc_k4.hpp) --
 // pd = 1, 2, 3 for LES grids of up to 248 / 488 / 968 levels, else the explicit-stack form
-template <typename T> KBwd<T> cons_kernel(int geo, int pd)
+template <typename T> KBwd<T> cons_kernel(int geo, int pd, int cb)
 {
-    static const KBwd<T> kc[4] = {k_backward_cons2<T, 0, 0, -1>, k_backward_cons2<T, 91, 160>, k_backward_cons2<T, 137, 512>,
-                                  k_backward_cons2<T, 19, 160>};
+    // compile-time geometries: the third form (spc_k4.hpp: products per cell, padded scans, layer means stashed in registers)
+    static const KBwd<T> k3[4][2] = {{nullptr, nullptr},
+                                     {k_backward_cons3<T, 91, 160, 1>, k_backward_cons3<T, 91, 160, 2>},
+                                     {k_backward_cons3<T, 137, 512, 1>, k_backward_cons3<T, 137, 512, 2>},
+                                     {k_backward_cons3<T, 19, 160, 1>, k_backward_cons3<T, 19, 160, 2>}};
+    if (geo != 0) return k3[geo][cb >= 2 ? 1 : 0];
     if constexpr (std::is_same<T, double>::value) {      // (the float twin, config 5's tolerance sweep, keeps the stack form)
         static const KBwd<T> kd[3] = {k_backward_cons2<T, 0, 0, 1>, k_backward_cons2<T, 0, 0, 2>, k_backward_cons2<T, 0, 0, 3>};
-        if (geo == 0 && pd >= 1 && pd <= 3) return kd[pd - 1];
+        if (pd >= 1 && pd <= 3) return kd[pd - 1];
     }
-    return kc[geo];
+    return k_backward_cons2<T, 0, 0, -1>;
+}
+
+// columns per workgroup of the third-form K4: one while the whole grid is resident at once (a single round: the most
+// parallelism per column), else two when that keeps more COLUMNS resident per CU (K4's rate follows them, spc_k4.hpp)
+template <typename T> int pick_cb_cons3(const spc_dims *d, int geo)
+{
+    size_t per_col, fixed;
+    lds_elems(d, 4, false, &per_col, &fixed, sizeof(T));
+    const size_t smem1 = (per_col + fixed) * sizeof(T), smem2 = (2 * per_col + fixed) * sizeof(T);
+    const bool two_fits = smem2 <= (size_t)MAX_LDS_BYTES;
+    if (d->cols_per_block > 0) return (d->cols_per_block >= 2 && two_fits) ? 2 : 1;
+    const int nb1 = blocks_per_cu(cons_kernel<T>(geo, 0, 1), smem1);
+    if (d->n_cols <= (int64_t)256 * nb1 || !two_fits) return 1;
+    const int nb2 = blocks_per_cu(cons_kernel<T>(geo, 0, 2), smem2);
+    return nb2 * 2 > nb1 ? 2 : 1;
 }
 
 // depth of numpy's pairwise recursion over at most nL elements (<= 8192: one chunk); -1: use the explicit stack
@@ -1211,7 +1265,7 @@ template <typename T> int choose_bwd(const spc_dims *d, bool cons, Choice *c)
     // PRE = false (8 waves per SIMD) pays between one round of workgroups and saturation: 1 025 ... 25 000 columns
     c->pre = (cons || sb || (pre_env >= 0 ? pre_env != 0 : (d->n_cols <= 1024 || d->n_cols > 25000))) ? 1 : 0;
     c->blk = sb ? BLOCK * sb : BLOCK;
-    c->cb = sb ? sb : (cons ? pick_cb(d, 4, false, sizeof(T), cons_kernel<T>(c->geo, cons_depth(d->nL)))
+    c->cb = sb ? sb : (cons ? (c->geo ? pick_cb_cons3<T>(d, c->geo) : pick_cb(d, 4, false, sizeof(T), cons_kernel<T>(0, cons_depth(d->nL), 0)))
                             : pick_cb(d, 1, false, sizeof(T), bwd_kernel<T>(c->geo, 0, BLOCK, c->pre)));
     size_t per_col, fixed;
     lds_elems(d, cons ? 4 : 1, false, &per_col, &fixed, sizeof(T));
@@ -1241,7 +1295,7 @@ template <typename T> int backward_impl(const spc_dims *d, const spc_backward_ar
     }
     Choice c;
     if ((rc = choose_bwd<T>(d, cons, &c))) return rc;
-    const KBwd<T> kern = cons ? cons_kernel<T>(c.geo, cons_depth(d->nL)) : bwd_kernel<T>(c.geo, c.wt, c.blk, c.pre);
+    const KBwd<T> kern = cons ? cons_kernel<T>(c.geo, cons_depth(d->nL), c.cb) : bwd_kernel<T>(c.geo, c.wt, c.blk, c.pre);
     if (!kern) return fail(SPC_ERR_UNSUPPORTED, "%sbackward: no kernel instantiated for this launch choice (internal)");
     if ((rc = ensure_lds(kern, c.smem, cons ? "backward (conservative)" : "backward"))) return rc;
     BwdP<T> p;
@@ -1527,7 +1581,7 @@ int spc_describe_launch(const spc_dims *d, int pass, int flags, int elem_size, c
         if (c.geo == 0)
             snprintf(name, sizeof(name), "k_backward_cons2<%s,0,0,pd=%d>", ty, elem_size == 8 ? cons_depth(d->nL) : -1);
         else
-            snprintf(name, sizeof(name), "k_backward_cons2<%s,%d,%d>", ty, GEO_NG[c.geo], GEO_NL[c.geo]);
+            snprintf(name, sizeof(name), "k_backward_cons3<%s,%d,%d,cb=%d>", ty, GEO_NG[c.geo], GEO_NL[c.geo], c.cb >= 2 ? 2 : 1);
     else
         snprintf(name, sizeof(name), "%s<%s>", c.kernel, ty);
     return snprintf(buf, (size_t)buflen, "%s cb=%d grid=%u block=%d lds=%lld", name, c.cb, c.grid, c.blk, (long long)c.smem);

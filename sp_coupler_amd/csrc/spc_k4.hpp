@@ -205,3 +205,202 @@ template <typename T, int NG = 0, int NL = 0, int PD = -1> __global__ __launch_b
     STAMP(4);
     STAMP(5);
 }
+
+// =================================================================================================================
+// K4, third form (round 4) for the compile-time level geometries: k_backward_cons3<T, NG, NL, CB>.
+// The stamps of the second form at config 3 (profiles/r04_k4_stamps.log) put 7.5 of a workgroup's 13.2 us into its two
+// compute phases -- 2.6 us for the cell scans, 4.8 us for the layer sums (K3's whole compute phase: 3.8 us) -- and the SQ
+// counters of round 3 6 x K3's LDS instructions.  What the sums did per term: z[i+1], z[i], w[i], q[i] (+ ql_ice[i]) from
+// LDS, a subtraction and two multiplications.  Here
+//   * the products the reference's temporaries hold are formed ONCE per cell while staging -- wq_f[i] = w[i] q_f[i] for the
+//     seven fields (ql_water = ql - ql_ice included, spcpl.py:402) next to w[i], and dz[i] = zh[i+1] - zh[i] once per
+//     workgroup for a shared grid -- so a term is wq_f[i] dz[i]: two LDS reads and one multiplication, same bits
+//     ((w q) dz, sputils.py:154: the same two roundings);
+//   * the cell scans run on a NaN-padded copy of zh with a compile-time trip count (su_count: 3 VALU instructions per step);
+//   * start_index is found while staging, by the thread that holds Zf[k] (left neighbour's value by a shuffle), so Zf
+//     is never staged;
+//   * the layer means do not get a region of their own: every lane keeps the means of its <= MAXIT (level, field) items in
+//     registers across a barrier and then writes them over the product arrays, which nobody reads any more.
+// LDS per column: A[8][nL+1] (wq_t | wq_qt | wq_ql | wq_ql_water | wq_ql_ice | wq_u | wq_v | w) | Zh[nG+1] | cell[nG] | start
+// index = 11.4 KB at 91 <-> 160 (second form: 15.2): a two-column workgroup takes 26.2 KB, six of them fit a CU.
+// CB: columns per workgroup (1 or 2), a template argument because the register stash needs its trip count.
+// =================================================================================================================
+constexpr int k4_sl(int nL) { return cfloor_pow2(nL - 1) == 64 ? 7 : cfloor_pow2(nL - 1) == 128 ? 8 : cfloor_pow2(nL - 1) == 256 ? 9
+                                   : cfloor_pow2(nL - 1) == 512 ? 10 : 0; }
+
+template <typename T, int NG, int NL, int CB> __global__ __launch_bounds__(BLOCK) void k_backward_cons3(const BwdP<T> p)
+{
+    static_assert(NG > 0 && NL > 1 && (CB == 1 || CB == 2), "compile-time geometry, one or two columns per workgroup");
+    const DimsP &d = p.d;
+    constexpr int nG = NG, nL = NL, nLp = NL + 1, tid_n = BLOCK;
+    constexpr int64_t pitchG = NG, pitchGh = NG + 1, pitchL = NL;
+    constexpr int P2 = cfloor_pow2(NL - 1), SL = k4_sl(NL), ZROW = 2 * P2 + 2;          // su_pad(P2): the padded zh row
+    constexpr int IPE = sizeof(T) / sizeof(int);
+    constexpr size_t o_Zh = (size_t)8 * nLp, o_cell = o_Zh + nG + 1, o_sidx = o_cell + (size_t)(nG + IPE - 1) / IPE, per_col = o_sidx + 1;
+    constexpr int MAXIT = (CB * NG * 8 + BLOCK - 1) / BLOCK;                              // (level, field) items per thread
+    static_assert(7 * NG <= 8 * (NL + 1), "the layer means must fit over the product arrays");
+    const int tid = threadIdx.x;
+    const int64_t col0 = (int64_t)slab_index(d.xcd_remap) * CB;
+    const int ncol = (int)((d.n_cols - col0) < CB ? (d.n_cols - col0) : CB);
+    T *const lds = reinterpret_cast<T *>(spc_smem);
+    T *const lzh = lds + (size_t)CB * per_col;                                           // zh rows, NaN-padded: [1 or CB][ZROW]
+    T *const ldz = lzh + (d.shared_grid ? ZROW : (size_t)CB * ZROW);                     // dz [nL - 1] (shared grid only)
+    const int n1 = ncol * nG;
+    STAMP(0);
+
+    // ---- stage: products per cell, the grid, the GCM half levels; start_index from Zf on the way -------------------------
+    for (int e = tid; e < ncol * nL; e += tid_n) {
+        const int c = e / nL, l = e - c * nL;
+        const int64_t o = (col0 + c) * pitchL + l;
+        const T t = p.t_d[o], qt = p.qt_d[o], ql = p.ql_d[o], qi = p.ql_ice_d[o], u = p.u_d[o], v = p.v_d[o], w = p.rhobf_d[o];
+        T *const s = lds + (size_t)c * per_col + l;
+        s[0] = w * t;                                                                    // sputils.py:152: w * q, per field
+        s[nLp] = w * qt;                                                                 // (order of spcpl.py:482-488)
+        s[2 * nLp] = w * ql;
+        s[3 * nLp] = w * (ql - qi);                                                      // ql_water, spcpl.py:402
+        s[4 * nLp] = w * qi;
+        s[5 * nLp] = w * u;
+        s[6 * nLp] = w * v;
+        s[7 * nLp] = w;
+    }
+    {
+        const T nan = T(0) / T(0);
+        const int nz = d.shared_grid ? ZROW : ncol * ZROW;
+        for (int e = tid; e < nz; e += tid_n) {
+            const int c = e / ZROW, j = e - c * ZROW;
+            lzh[e] = j < nL ? (d.shared_grid ? p.zh[j] : p.zh[(col0 + c) * pitchL + j]) : nan;
+        }
+        if (d.shared_grid)
+            for (int e = tid; e < nL - 1; e += tid_n) ldz[e] = p.zh[e + 1] - p.zh[e];    // sputils.py:146 / 154 / 159: z[i+1] - z[i]
+    }
+    for (int e = tid; e < ncol * (nG + 1); e += tid_n) {
+        const int c = e / (nG + 1), k = e - c * (nG + 1);
+        const int64_t col = col0 + c, gh = col * pitchGh;
+        T *const s = lds + (size_t)c * per_col;
+        const T zs = p.Zghalf ? p.Zghalf[gh + nG] : T(0);
+        s[o_Zh + k] = p.Zh ? p.Zh[gh + k] : div_grav(p.Zghalf[gh + k] - zs);             // spcpl.py:197
+        // start_index = numpy.searchsorted(-Zf, -h[-1]) (spcpl.py:498): the first k with !(-Zf[k] < -h_top).  The thread that
+        // holds Zf[k] decides with its left neighbour's value (shuffle; a wave's first lane loads it): one writer per
+        // column for heights the predicate partitions (the reference's: monotone); k == nG closes the all-above case.
+        const int kk = k < nG ? k : nG - 1;
+        const int64_t g = col * pitchG + kk;
+        const T zfk = p.Zf ? p.Zf[g] : div_grav(p.Zgfull[g] - zs);                       // spcpl.py:198
+        T prev = __shfl_up(zfk, 1);
+        if ((tid & 63) == 0 && k > 0 && k < nG) prev = p.Zf ? p.Zf[g - 1] : div_grav(p.Zgfull[g - 1] - zs);
+        const T key = -p.zf[d.shared_grid ? (int64_t)(nL - 1) : col * pitchL + (nL - 1)];        // -h[-1]
+        const bool less_k = np_lt(-zfk, key), less_prev = k > 0 && np_lt(-prev, key);
+        int *const sidx = reinterpret_cast<int *>(s + o_sidx);
+        if (k < nG && !less_k && (k == 0 || less_prev)) sidx[0] = k;
+        if (k == nG && less_k) sidx[0] = nG;                                             // (zfk is Zf[nG-1] here)
+    }
+    __syncthreads();
+    STAMP(1);
+
+    // ---- per GCM level, once: the LES cells of the layer [Zh[k+1], Zh[k]] (integral()'s scans, sputils.py:113-127).
+    //      ia = -1: layer above the LES top (Q stays 0, sputils.py:187); -2: an end point outside zh (None -> NaN);
+    //      ib < 0 encodes sign = -1 (sputils.py:117-120).
+    for (int e = tid; e < n1; e += tid_n) {
+        const int c = e / nG, k = e - c * nG;
+        T *const s = lds + (size_t)c * per_col;
+        const T *const z = d.shared_grid ? lzh : lzh + (size_t)c * ZROW;
+        const T *const Zh = s + o_Zh;
+        int ia = -1, ib = -1;
+        if (Zh[k] < z[nL - 1]) {                                                         // sputils.py:187
+            T a = Zh[k + 1], b = Zh[k];
+            if (a < z[0] || a > z[nL - 1] || b < z[0] || b > z[nL - 1]) {
+                ia = -2;                                                                 // sputils.py:113-115
+            } else {
+                const bool swap = a > b;                                                 // sputils.py:117-120
+                if (swap) { const T t = a; a = b; b = t; }
+                // `while z[i+1] < a: i += 1` = the number of k' >= 1 with z[k'] < a (z[nL-1] < a is false: a <= z[nL-1])
+                ia = su_count<SL>(z + 1, P2, [&](T zk) { return zk < a; });              // sputils.py:122-124
+                ib = su_count<SL>(z + 1, P2, [&](T zk) { return zk < b; });              // sputils.py:125-127
+                if (ib < ia) ib = ia;
+                if (swap) ib = -ib - 2;
+            }
+        }
+        reinterpret_cast<int *>(s + o_cell)[k] = (ia & 0xffff) | (ib * 65536);
+    }
+    __syncthreads();
+    STAMP(2);
+
+    // ---- layer means: thread = (column, GCM level, field); lane & 7 = field, 7 = the weight sum; kept in registers ------
+    T Xr[MAXIT];
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int e = tid + it * BLOCK;
+        T X = T(0);                                                                      // Q = zeros (sputils.py:185)
+        if (e < n1 * 8) {
+            const int f = e & 7, ck = e >> 3, c = ck / nG, k = ck - c * nG;
+            const T *const s = lds + (size_t)c * per_col;
+            const T *const z = d.shared_grid ? lzh : lzh + (size_t)c * ZROW;
+            const int pk = reinterpret_cast<const int *>(s + o_cell)[k], ia = (int)(short)(pk & 0xffff);
+            if (ia == -2) {
+                X = T(0) / T(0);                                                         // Q[i] = None stores NaN (numpy 2.x)
+            } else if (ia >= 0) {
+                int ib = pk >> 16;
+                const bool swap = ib < 0;
+                if (swap) ib = -ib - 2;
+                const T sign = swap ? T(-1) : T(1);
+                const int cnt = ib - ia + 1;
+                const T *const a = s + (size_t)f * nLp + ia;                             // this lane's products (lane 7: the weights)
+                T S;
+                if (d.shared_grid) {
+                    const T *const dz = ldz + ia;
+                    S = T(0) + vn_pw<vn_pw_depth(NL)>([&](int i) { return a[i] * dz[i]; }, 0, cnt);       // sputils.py:152 / 157
+                } else {
+                    const T *const zz = z + ia;
+                    S = T(0) + vn_pw<vn_pw_depth(NL)>([&](int i) { return a[i] * (zz[i + 1] - zz[i]); }, 0, cnt);
+                }
+                const T za = s[o_Zh + k + 1], zb = s[o_Zh + k];                          // a, b of integral() before the swap
+                const T da = (swap ? zb : za) - z[ia], db = z[ib + 1] - (swap ? za : zb);   // sputils.py:154,159
+                const T num = (S - a[0] * da) - a[cnt - 1] * db;                         // S - Sa - Sb / Sw - Swa - Swb
+                const T den = __shfl(num, (threadIdx.x & 63) | 7);                       // the level's weight lane
+                X = num / den * sign;                                                    // sputils.py:161
+            }
+        }
+        Xr[it] = X;
+    }
+    __syncthreads();                                                                     // nobody reads the products any more
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int e = tid + it * BLOCK;
+        if (e < n1 * 8) {
+            const int f = e & 7, ck = e >> 3, c = ck / nG, k = ck - c * nG;
+            if (f < 7) lds[(size_t)c * per_col + (size_t)f * nG + k] = Xr[it];           // X[7][nG] over the product arrays
+        }
+    }
+    __syncthreads();
+    STAMP(3);
+
+    // ---- tendencies: flat over the [ncol x nG] slab, as K3 (spcpl.py:498, 518-533) --------------------------------------
+    for (int e = tid; e < n1; e += tid_n) {
+        const int c = e / nG, k = e - c * nG;
+        const int64_t col = col0 + c, cg = col * pitchG, g = cg + k;
+        const T *const s = lds + (size_t)c * per_col;
+        const GcmIn<T> in = load_gcm(p, g, cg + (nG - 1 - k));
+        const int start_index = reinterpret_cast<const int *>(s + o_sidx)[0];
+        const T X0 = s[k], X1 = s[nG + k], X2 = s[2 * nG + k], X3 = s[3 * nG + k], X4 = s[4 * nG + k], X5 = s[5 * nG + k], X6 = s[6 * nG + k];
+        T f_T = p.factor * (X0 - in.tt) / p.dt;                                          // spcpl.py:518
+        T f_SH = p.factor * ((X1 - X2) - in.sh) / p.dt;                                  // spcpl.py:519
+        T f_QL = p.factor * (X3 - in.ql) / p.dt;                                         // spcpl.py:520
+        T f_QI = p.factor * (X4 - in.qi) / p.dt;                                         // spcpl.py:521
+        T f_U = p.factor * (X5 - in.u) / p.dt;                                           // spcpl.py:524
+        T f_V = p.factor * (X6 - in.v) / p.dt;                                           // spcpl.py:525
+        T f_A = p.factor * (in.a_d - in.a) / p.dt;                                       // spcpl.py:526
+        if (k < start_index) {                                                           // spcpl.py:527-533
+            const T zero = T(0);
+            f_T *= zero; f_SH *= zero; f_QL *= zero; f_QI *= zero; f_U *= zero; f_V *= zero; f_A *= zero;
+        }
+        p.f_T[g] = f_T;
+        p.f_SH[g] = f_SH;
+        p.f_QL[g] = f_QL;
+        p.f_QI[g] = f_QI;
+        p.f_U[g] = f_U;
+        p.f_V[g] = f_V;
+        p.f_A[g] = f_A;
+        if (p.start_index && k == 0) p.start_index[col] = start_index;
+    }
+    STAMP(4);
+    STAMP(5);
+}

@@ -76,31 +76,7 @@ template <typename T> __device__ __forceinline__ T *su_at(T *base, int off)
     return (T *)((char *)base + (unsigned)(off * (int)sizeof(T)));
 }
 
-// ---- searches on LDS rows: fixed trip count, no bounds check -------------------------------------------------------
-// The three searches of this file -- numpy.interp's bracket (count of xp[i] <= x), numpy.searchsorted (count of entries
-// in front of the insertion point) and integral()'s cell scan (count of z[k] < a) -- are prefix counts over an ascending
-// row.  A staged row is PADDED WITH NaN up to 2 p2 entries (p2 = the largest power of two <= its length): the greedy
-// power-of-two descent of upper_count() then needs no `t <= n` test, because no predicate used here advances on a NaN
-// (searchsorted with a NaN key is the one exception and clamps), and with the trip count a template argument (SL =
-// log2 p2 + 1) every probe is one ds_read with an immediate offset + compare + select: 3 VALU instructions per step
-// instead of 8-12 (round 4: the first K7 generation was bound by VALU issue, 100-150 instructions per output,
-// profiles/r04_k7_counters.log).  SL = 0: the same descent with p2 at run time; SL = -1: nothing staged (rows beyond
-// the LDS), the operators fall back to the loops on global memory.
-__host__ __device__ inline int su_pad(int p2) { return 2 * p2 + 2; }      // entries of a padded row (+2: rows off each other's banks)
-
-template <int SL, typename T, typename Pred> __device__ __forceinline__ int su_count(const T *row, int p2, const Pred &adv)
-{
-    int pos = 0;
-    if constexpr (SL > 0) {
-#pragma unroll
-        for (int s = 1 << (SL - 1); s > 0; s >>= 1)
-            if (adv(row[pos + s - 1])) pos += s;
-    } else {
-        for (int s = p2; s > 0; s >>= 1)
-            if (adv(row[pos + s - 1])) pos += s;
-    }
-    return pos;
-}
+// (su_pad / su_count -- the fixed-trip searches on NaN-padded LDS rows -- live in spc_hip.hip: K4 uses them too)
 
 // nrow rows of n elements (row r at src + r * pitch) into LDS rows of `stride` entries, the tail of every row NaN;
 // U entries of a thread in flight before its first LDS store; (row, entry) stepped, never divided

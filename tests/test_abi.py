@@ -114,7 +114,7 @@ def test_describe_launch_names_the_instantiation_the_launcher_would_pick(lib):
     assert k3(4096, nG=19) == "k_backward<f64,19,160,wt=1,blk=256,pre=0>"
     full = _abi.describe_launch(lib, d(4096), 0, 3)
     assert full.startswith("k_forward<f64,full,91,160,wt=0,blk=256,pre=0> cb=")        # FULL: plain stores only
-    assert _abi.describe_launch(lib, d(4096), 4, 0).startswith("k_backward_cons2<f64,91,160> cb=")
+    assert _abi.describe_launch(lib, d(4096), 4, 0).startswith("k_backward_cons3<f64,91,160,cb=")
     # K4's footprint is what lets FIVE two-column workgroups share a CU: 25 of gfx950's 1 280-byte LDS allocation granules
     k4 = _abi.describe_launch(lib, d(35718), 4, 0)
     assert " cb=2 " in k4 and int(k4.split("lds=")[1]) <= 25 * 1280, k4

@@ -228,7 +228,10 @@ template <typename T, int NG = 0, int NL = 0, int PD = -1> __global__ __launch_b
 constexpr int k4_sl(int nL) { return cfloor_pow2(nL - 1) == 64 ? 7 : cfloor_pow2(nL - 1) == 128 ? 8 : cfloor_pow2(nL - 1) == 256 ? 9
                                    : cfloor_pow2(nL - 1) == 512 ? 10 : 0; }
 
-template <typename T, int NG, int NL, int CB> __global__ __launch_bounds__(BLOCK) void k_backward_cons3(const BwdP<T> p)
+#ifndef SPC_K4_WAVES     // waves per SIMD the register allocator is asked to fit (6 = 80 VGPRs: six workgroups per CU)
+#define SPC_K4_WAVES 6
+#endif
+template <typename T, int NG, int NL, int CB> __global__ __launch_bounds__(BLOCK, (NL <= 160 ? SPC_K4_WAVES : 1)) void k_backward_cons3(const BwdP<T> p)
 {
     static_assert(NG > 0 && NL > 1 && (CB == 1 || CB == 2), "compile-time geometry, one or two columns per workgroup");
     const DimsP &d = p.d;

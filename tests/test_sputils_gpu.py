@@ -247,6 +247,41 @@ def test_interp_left_right_on_the_device(sputils):
         assert_bits("interp %s" % kw, sputils.interp(x, xp, fp, **kw), want)
 
 
+@pytest.mark.parametrize("n", [1, 2, 5, 40, 64, 91, 127, 128, 130, 300, 600, 1100, 5000])
+def test_every_search_depth_and_the_unstaged_rows(sputils, n):
+    """round 4: the staged kernels search NaN-padded LDS rows with a trip count fixed at compile time for rows of 64-1023
+    entries (SL 7-10), at run time otherwise (SL 0), and rows beyond the LDS (5000 entries) read global memory (SL -1):
+    every path against NumPy, shared and per-row sample arrays, exact hits, values outside, NaN / inf queries"""
+    rng = numpy.random.default_rng(100 + n)
+    rows = 37
+    xp = numpy.sort(rng.uniform(0, 1e4, size=(rows, n)), axis=1)
+    fp = rng.normal(size=(rows, n))
+    x = rng.uniform(-50, 1.005e4, size=(rows, 23))
+    x[:, 0], x[:, 1], x[:, 2] = xp[:, 0], xp[:, -1], xp[:, n // 2]          # exact hits incl. both ends
+    x[3, 5], x[4, 6], x[5, 7] = numpy.nan, numpy.inf, -numpy.inf
+    assert_bits("interp n=%d" % n, sputils.interp(x, xp, fp), _interp_rows(x, xp, fp))
+    assert_bits("interp shared xp n=%d" % n, sputils.interp(x, xp[0], fp), _interp_rows(x, xp[0], fp))
+    for side in ("left", "right"):
+        want = numpy.stack([numpy.searchsorted(xp[r], x[r], side=side) for r in range(rows)])
+        assert numpy.array_equal(sputils.searchsorted(xp, x, side=side), want), (n, side)
+        want = numpy.stack([numpy.searchsorted(xp[0], x[r], side=side) for r in range(rows)])
+        assert numpy.array_equal(sputils.searchsorted(xp[0], x, side=side), want), (n, side, "shared")
+    if n >= 2:                                                            # the fine grid of interp_c: n points, n - 1 cells
+        zh = numpy.cumsum(rng.uniform(0.5, 30, size=(rows, n)), axis=1)
+        Zh = numpy.sort(rng.uniform(zh[:, :1] - 5, zh[:, -1:] * 1.1, size=(rows, 12)), axis=1)[:, ::-1].copy()
+        Zh[:, -1] = zh[:, 0]                                              # a layer that ends exactly on the grid's first point
+        q, rho = rng.normal(size=(rows, n - 1)), rng.uniform(0.5, 1.3, size=(rows, n - 1))
+        with numpy.errstate(all="ignore"):
+            want = numpy.stack([orc.interp_c(Zh[r], zh[r], q[r], rho[r]) for r in range(rows)])
+            want_rho = numpy.stack([orc.interp_rho(Zh[r], zh[0], rho[r]) for r in range(rows)]) if n <= 1100 else None
+        assert_bits("interp_c n=%d" % n, sputils.interp_c(Zh, zh, q, rho), want)
+        if want_rho is not None:
+            Zh0 = numpy.sort(rng.uniform(zh[0, 0], zh[0, -1], size=(rows, 12)), axis=1)[:, ::-1].copy()
+            with numpy.errstate(all="ignore"):
+                want_rho = numpy.stack([orc.interp_rho(Zh0[r], zh[0], rho[r]) for r in range(rows)])
+            assert_bits("interp_rho shared zh n=%d" % n, sputils.interp_rho(Zh0, zh[0], rho), want_rho)
+
+
 def test_float32_engine_runs_the_helpers():
     from sp_coupler_amd.engine import Engine
     eng = Engine("cuda:0", dtype=torch.float32)

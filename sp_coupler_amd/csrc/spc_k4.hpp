@@ -228,6 +228,10 @@ template <typename T, int NG = 0, int NL = 0, int PD = -1> __global__ __launch_b
 constexpr int k4_sl(int nL) { return cfloor_pow2(nL - 1) == 64 ? 7 : cfloor_pow2(nL - 1) == 128 ? 8 : cfloor_pow2(nL - 1) == 256 ? 9
                                    : cfloor_pow2(nL - 1) == 512 ? 10 : 0; }
 
+// (the unroll request of the register-stash loop is not honoured for the 137 <-> 512 instantiations -- their loop body, two
+//  levels of numpy's recursion, is too large -- where the stash is then addressed through the loop counter: no scratch either)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wpass-failed"
 #ifndef SPC_K4_WAVES     // waves per SIMD the register allocator is asked to fit (6 = 80 VGPRs: six workgroups per CU)
 #define SPC_K4_WAVES 6
 #endif
@@ -407,3 +411,4 @@ template <typename T, int NG, int NL, int CB> __global__ __launch_bounds__(BLOCK
     STAMP(4);
     STAMP(5);
 }
+#pragma clang diagnostic pop

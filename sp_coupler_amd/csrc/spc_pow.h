@@ -20,6 +20,19 @@
 #include <math.h>
 #define SPC_POW_FN static inline
 #endif
+/* 1 / x to (at least) double precision.  Device: v_rcp_f64 refined by two Newton steps (what the compiler's own division
+ * expansion starts with) -- the two quotients below then cost 10 instructions instead of two IEEE divisions (~30); host:
+ * the correctly rounded quotient.  The two differ by a few 2^-53, which only enters through f_lo (itself < 2^-52 f). */
+#ifdef __HIP_DEVICE_COMPILE__
+SPC_POW_FN double spc_pow_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+    return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+}
+#else
+SPC_POW_FN double spc_pow_rcp(double x) { return 1.0 / x; }
+#endif
 
 SPC_POW_FN double spc_pow_pos(double x, double y)
 {
@@ -29,8 +42,9 @@ SPC_POW_FN double spc_pow_pos(double x, double y)
     if (m < 0.70710678118654752440) { m *= 2.0; e -= 1; }            /* [sqrt 1/2, sqrt 2) */
     const double num = m - 1.0;                                      /* exact */
     const double den = m + 1.0, den_lo = m - (den - 1.0);            /* m + 1 = den + den_lo exactly */
-    const double f = num / den;
-    const double f_lo = (__builtin_fma(-f, den, num) - f * den_lo) / den;     /* (m-1)/(m+1) = f + f_lo */
+    const double rc = spc_pow_rcp(den);
+    const double f = num * rc;                                       /* any f within a few ulp of the quotient will do: */
+    const double f_lo = (__builtin_fma(-f, den, num) - f * den_lo) * rc;      /* (m-1)/(m+1) = f + f_lo, f_lo from the exact remainder */
     const double s = f * f;
     double P = 2.0 / 21.0;
     P = __builtin_fma(P, s, 2.0 / 19.0); P = __builtin_fma(P, s, 2.0 / 17.0); P = __builtin_fma(P, s, 2.0 / 15.0);

@@ -14,7 +14,7 @@ for d in ("sq_k4", "sq_k4b"):
     for f in glob.glob("gpurun_out/%s/**/*counter_collection.csv" % d, recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            name = "K4" if "k_backward_cons2" in k else ("K3" if "k_backward" in k else ("K1" if "k_forward" in k else None))
+            name = "K4" if "k_backward_cons" in k else ("K3" if "k_backward" in k else ("K1" if "k_forward" in k else None))
             if name:
                 agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for kern in sorted(agg):

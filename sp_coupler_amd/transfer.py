@@ -46,8 +46,16 @@ class Arena:
         """the compute stream every copy of this buffer is ordered against"""
         return self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
 
-    def _copy(self, dst, src, what, nbytes, stream):
-        """one async copy issued on ``stream`` (torch issues copies on ITS current stream: make ``stream`` that)"""
+    def _copy(self, dst, src, what, nbytes, stream, current=False):
+        """one async copy issued on ``stream`` (torch issues copies on ITS current stream: make ``stream`` that, unless the
+        caller knows it is the current one already -- entering the stream context costs ~10 us of host time per copy)"""
+        if current:
+            if trace is not None:
+                with trace.region(what, nbytes, self.device):
+                    dst.copy_(src, non_blocking=True)
+            else:
+                dst.copy_(src, non_blocking=True)
+            return
         with torch.cuda.stream(stream):
             if trace is not None:
                 with trace.region(what, nbytes, self.device):
@@ -68,10 +76,13 @@ class Arena:
 
     def writable(self, name):
         """wait until the last upload of ``name`` has left the pinned host buffer (call before refilling it on the
-        host).  Free in the normal call order: a step waits for its results, hence for the kernel behind the uploads."""
+        host).  Free in the normal call order: a step waits for its results, hence for the kernel behind the uploads.
+        One wait serves every array the same copy carried."""
         ev = self.sent.pop(name, None)         # (an array collected for the copy at the next fence() is not on the wire)
         if ev is not None:
             ev.synchronize()
+            if len(self.sent) and any(e is ev for e in self.sent.values()):
+                self.sent = {k: e for k, e in self.sent.items() if e is not ev}
 
     def _names_in(self, lo, hi):
         return [nm for nm in self.begin if lo <= self.begin[nm] and self.end[nm] <= hi]
@@ -81,7 +92,7 @@ class Arena:
         if self.dev is not self.host:
             n = self.nbytes if upto is None else self.end[upto]
             cur = self._cur()
-            self._copy(self.dev[:n], self.host[:n], what, n, cur)
+            self._copy(self.dev[:n], self.host[:n], what, n, cur, current=self.stream is None)
             self._mark_sent(self._names_in(0, n), cur)
 
     def download(self, upto=None, what="d2h", start=None):
@@ -92,7 +103,7 @@ class Arena:
             n = self.nbytes if upto is None else self.end[upto]
             o = 0 if start is None else self.begin[start]
             cur = self._cur()
-            self._copy(self.host[o:n], self.dev[o:n], what, n - o, cur)
+            self._copy(self.host[o:n], self.dev[o:n], what, n - o, cur, current=self.stream is None)
             if self.done is None:
                 self.done = torch.cuda.Event()
             self.done.record(cur)
@@ -129,7 +140,7 @@ class Arena:
         if self.deferred is not None:
             lo, hi = self.deferred
             self.deferred = None
-            self._copy(self.dev[lo:hi], self.host[lo:hi], self.deferred_what, hi - lo, cur)
+            self._copy(self.dev[lo:hi], self.host[lo:hi], self.deferred_what, hi - lo, cur, current=self.stream is None)
             self._mark_sent(self._names_in(lo, hi), cur)
         if self.pushed:
             cur.wait_stream(self.side)

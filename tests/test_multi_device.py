@@ -212,3 +212,6 @@ def test_bench_in_process_extra_runs_on_two_engines():
     import bench
     r = bench.in_process_all_gpus([0, 0], 1.0, 900.0, argparse.Namespace(cols=6000, cols_per_block=0, steps=3, warmup=1))
     assert r["value"] > 0 and r["distinct_devices"] == 1 and "rows 0-3000" in r["partition"]
+    # every device's row block proves itself against the plain-C oracle (first and last row of the block included)
+    assert r["verified"] is True and [c["rows"] for c in r["verified_detail"]] == [[0, 3000], [3000, 6000]]
+    assert all(c["first_row"] == 0 and c["last_row"] == 2999 and c["failures"] == [] for c in r["verified_detail"])

@@ -32,6 +32,13 @@
 
 #pragma clang fp contract(off)
 
+// spc_pow's coefficients as a __constant__ table with EXTERNAL linkage (file scope, outside the unnamed namespace below): the
+// standalone exner kernel reads them into scalar registers (spc_pow.h: spc_pow_pos_tab); an internal table would be proved
+// constant and folded back into literals
+#include "spc_pow_coefs.h"
+__constant__ double spc_pow_coef_table[21] = {SPC_POW_COEFS};
+#define SPC_POW_TABLE spc_pow_coef_table
+
 // Diagnostic builds only (never the shipped library; tools/exp_variants.sh): apportion kernel time.
 //   -DSPC_EXP=1  every division becomes a multiplication by v_rcp_f64 (NOT bit-exact)
 //   -DSPC_EXP=3  as 1, and pow() becomes a multiplication
@@ -95,9 +102,20 @@ __device__ __forceinline__ double spc_pow(double x, double y)
     }
     return spc_pow_pos(x, y);
 }
+// the same with the polynomial coefficients in scalar registers (spc_pow.h: spc_pow_pos_tab): the standalone exner operator
+__device__ __forceinline__ double spc_pow_scalar_coef(double x, double y)
+{
+    if (!(x > 0.0 && x <= 1.7976931348623157e308)) return spc_pow(x, y);      // the special values, as above
+    return spc_pow_pos_tab(x, y);
+}
 #endif
 __device__ __forceinline__ float spc_pow(float x, float y) { return powf(x, y); }
 #endif
+
+#if SPC_FASTPOW || SPC_EXP >= 2 || defined(SPC_OCML_POW)      // diagnostic builds: one pow for everything
+__device__ __forceinline__ double spc_pow_scalar_coef(double x, double y) { return spc_pow(x, y); }
+#endif
+__device__ __forceinline__ float spc_pow_scalar_coef(float x, float y) { return spc_pow(x, y); }
 
 // Streaming accesses of the hot kernels: every input element is read once and every output written
 // once per launch.  -DSPC_NT=1 marks them non-temporal (experiment switch).

@@ -34,46 +34,29 @@ SPC_POW_FN double spc_pow_rcp(double x)
 SPC_POW_FN double spc_pow_rcp(double x) { return 1.0 / x; }
 #endif
 
-SPC_POW_FN double spc_pow_pos(double x, double y)
-{
-    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10, LOG2E = 1.44269504088896338700e+00;
-    int e;
-    double m = frexp(x, &e);                                         /* [0.5, 1) */
-    if (m < 0.70710678118654752440) { m *= 2.0; e -= 1; }            /* [sqrt 1/2, sqrt 2) */
-    const double num = m - 1.0;                                      /* exact */
-    const double den = m + 1.0, den_lo = m - (den - 1.0);            /* m + 1 = den + den_lo exactly */
-    const double rc = spc_pow_rcp(den);
-    const double f = num * rc;                                       /* any f within a few ulp of the quotient will do: */
-    const double f_lo = (__builtin_fma(-f, den, num) - f * den_lo) * rc;      /* (m-1)/(m+1) = f + f_lo, f_lo from the exact remainder */
-    const double s = f * f;
-    double P = 2.0 / 21.0;
-    P = __builtin_fma(P, s, 2.0 / 19.0); P = __builtin_fma(P, s, 2.0 / 17.0); P = __builtin_fma(P, s, 2.0 / 15.0);
-    P = __builtin_fma(P, s, 2.0 / 13.0); P = __builtin_fma(P, s, 2.0 / 11.0); P = __builtin_fma(P, s, 2.0 / 9.0);
-    P = __builtin_fma(P, s, 2.0 / 7.0); P = __builtin_fma(P, s, 2.0 / 5.0); P = __builtin_fma(P, s, 2.0 / 3.0);
-    const double lo = __builtin_fma(f * s, P, 2.0 * f_lo);           /* log m = 2 f + lo */
-    const double ed = (double)e;
-    const double L_hi = ed * LN2_HI;                                 /* exact: LN2_HI has 32 significant bits */
-    const double f2 = 2.0 * f;
-    const double A = L_hi + f2, bb = A - L_hi;
-    const double a_err = (L_hi - (A - bb)) + (f2 - bb);              /* TwoSum: L_hi + 2 f = A + a_err exactly */
-    const double B = __builtin_fma(ed, LN2_LO, lo) + a_err;          /* log x = A + B */
-    const double t_hi = y * A;
-    const double t_lo = __builtin_fma(y, B, __builtin_fma(y, A, -t_hi));
-    const double t = t_hi + t_lo, tl = t_lo - (t - t_hi);            /* y log x = t + tl */
-    const double n = rint(t * LOG2E);
-    const double r0 = __builtin_fma(-n, LN2_HI, t);                  /* exact */
-    const double c = __builtin_fma(-n, LN2_LO, tl);
-    const double r = r0 + c, r_lo = c - (r - r0);                    /* t - n ln2 = r + r_lo */
-    double q = 1.0 / 6227020800.0;
-    q = __builtin_fma(q, r, 1.0 / 479001600.0); q = __builtin_fma(q, r, 1.0 / 39916800.0); q = __builtin_fma(q, r, 1.0 / 3628800.0);
-    q = __builtin_fma(q, r, 1.0 / 362880.0); q = __builtin_fma(q, r, 1.0 / 40320.0); q = __builtin_fma(q, r, 1.0 / 5040.0);
-    q = __builtin_fma(q, r, 1.0 / 720.0); q = __builtin_fma(q, r, 1.0 / 120.0); q = __builtin_fma(q, r, 1.0 / 24.0);
-    q = __builtin_fma(q, r, 1.0 / 6.0);                              /* exp r = 1 + r + r^2 / 2 + r^3 q */
-    const double rr = r * r, rr_err = __builtin_fma(r, r, -rr);      /* r^2 = rr + rr_err exactly */
-    const double h = 0.5 * rr;
-    const double hi = 1.0 + r, e1 = r - (hi - 1.0);                  /* 1 + r = hi + e1 exactly (Fast2Sum) */
-    const double hi2 = hi + h, e2 = h - (hi2 - hi);                  /* hi + h = hi2 + e2 exactly (hi >= 0.65 > h) */
-    const double tail = __builtin_fma(rr * r, q, __builtin_fma(r_lo, r, r_lo));        /* r^3 q + r_lo (1 + r): < 0.008 */
-    return ldexp(hi2 + (((e1 + e2) + 0.5 * rr_err) + tail), (int)n); /* the only rounding of full size */
-}
+#include "spc_pow_coefs.h"
+#ifdef __HIPCC__
+static __device__ const double spc_pow_lit[21] = {SPC_POW_COEFS};
+#else
+static const double spc_pow_lit[21] = {SPC_POW_COEFS};
+#endif
+/* spc_pow_pos: coefficients as literals (constant indices into a const array fold).  What K1 / K5 / K6 use: they are bound by
+ * memory and short of scalar registers. */
+#define SPC_POW_NAME spc_pow_pos
+#define SPC_PC(i) spc_pow_lit[i]
+#include "spc_pow_body.inc"
+#undef SPC_POW_NAME
+#undef SPC_PC
+#if defined(__HIPCC__) && defined(SPC_POW_TABLE)
+/* spc_pow_pos_tab: the same operations with the coefficients read from the __constant__ table SPC_POW_TABLE, i.e. held in SCALAR
+ * registers and used as the scalar operand of the fma -- a 64-bit literal costs two v_mov per use instead (26 % of the VALU
+ * instructions of a pow).  For the standalone exner operator, which is bound by VALU issue (profiles/r04_k7_counters.log).  The
+ * table must have EXTERNAL linkage (the includer defines it at file scope): one the optimizer can prove constant is folded back
+ * into literals.  Same operations, same bits. */
+#define SPC_POW_NAME spc_pow_pos_tab
+#define SPC_PC(i) SPC_POW_TABLE[i]
+#include "spc_pow_body.inc"
+#undef SPC_POW_NAME
+#undef SPC_PC
+#endif
 #endif

@@ -144,7 +144,7 @@ template <typename T, int WT> __global__ __launch_bounds__(SU_THREADS) void k_ex
         v[u] = i < n ? ldg(p + i) : T(1);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = spc_pow(div_pref0(v[u]), y);
+    for (int u = 0; u < 4; ++u) v[u] = spc_pow_scalar_coef(div_pref0(v[u]), y);      // coefficients as scalar operands
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int64_t i = i0 + u * SU_THREADS;

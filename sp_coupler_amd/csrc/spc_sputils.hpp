@@ -10,7 +10,7 @@
 // once.  A "row" is one independent 1-D problem; arrays are [n_rows x n] with an element pitch between rows, pitch 0 =
 // one row shared by all.
 //
-// Round 4 (second generation; counters of the first in profiles/r04_k7_baseline.log): the first generation moved exactly its
+// Round 4 (second generation; counters of the first and of this one in profiles/r04_k7_counters.log): the first generation moved exactly its
 // algorithmic bytes (PMC traffic 1.00-1.06 x) but slowly -- its LDS staging went through ONE pointer that could be LDS or
 // global, so every access was a FLAT one (3 LDS instructions per wave, 30 flat loads: interp); interp_c summed w q dz with
 // 3-4 LDS reads and 2 multiplications per term in two passes (1 279 VALU instructions per wave); rms gave a whole row to
@@ -23,7 +23,11 @@
 //     of LDS values, run side by side in ONE numpy-ordered pass (Pair2);
 //   * rms: 8 lanes per row = the 8 accumulators of numpy's leaf, combined by shuffles in numpy's order (64-B segments,
 //     no LDS, 8 x the parallelism per row);
-//   * exner: 4 elements per thread, loads up front, 4 independent pow chains, one pass over an uncapped grid.
+//   * exner: 4 elements per thread, loads up front, 4 independent pow chains, one pass over an uncapped grid; the pow's 21
+//     polynomial coefficients come from a __constant__ table, i.e. scalar registers (spc_pow_scalar_coef: a 64-bit literal costs
+//     two v_mov per use, 26 % of the instructions of a pow; the operator is bound by VALU issue);
+//   * the searches run on NaN-padded LDS rows with a fixed trip count (su_count, spc_hip.hip), addresses are a uniform base + a
+//     32-bit byte offset (su_at).
 #pragma once
 
 constexpr int SU_THREADS = 256;

@@ -808,18 +808,29 @@ template <typename T> __device__ __forceinline__ int scan_cell(const T *z, int n
 // the LDS), the operators fall back to the loops on global memory.
 __host__ __device__ inline int su_pad(int p2) { return 2 * p2 + 2; }      // entries of a padded row (+2: rows off each other's banks)
 
-template <int SL, typename T, typename Pred> __device__ __forceinline__ int su_count(const T *row, int p2, const Pred &adv)
+// the descent carries the ADDRESS of the first entry not counted (row + count), not the count: a step is then one
+// ds_read at [address + immediate], one add, one compare and one select -- no index-to-address shift per probe
+template <int SL, typename T, typename Pred> __device__ __forceinline__ const T *su_seek(const T *row, int p2, const Pred &adv)
 {
-    int pos = 0;
+    const T *p = row;
     if constexpr (SL > 0) {
 #pragma unroll
-        for (int s = 1 << (SL - 1); s > 0; s >>= 1)
-            if (adv(row[pos + s - 1])) pos += s;
+        for (int s = 1 << (SL - 1); s > 0; s >>= 1) {
+            const T *const nx = p + s;
+            p = adv(p[s - 1]) ? nx : p;
+        }
     } else {
-        for (int s = p2; s > 0; s >>= 1)
-            if (adv(row[pos + s - 1])) pos += s;
+        for (int s = p2; s > 0; s >>= 1) {
+            const T *const nx = p + s;
+            p = adv(p[s - 1]) ? nx : p;
+        }
     }
-    return pos;
+    return p;
+}
+
+template <int SL, typename T, typename Pred> __device__ __forceinline__ int su_count(const T *row, int p2, const Pred &adv)
+{
+    return (int)(((unsigned)(size_t)su_seek<SL>(row, p2, adv) - (unsigned)(size_t)row) / (unsigned)sizeof(T));   // 32-bit: LDS addresses
 }
 
 #include "spc_k4.hpp"
@@ -995,11 +1006,16 @@ template <typename KernelT> int pick_cb(const spc_dims *d, int pass, bool with_i
 // Launches that write no more than the aggregate L2 (32 MiB) store write-through: otherwise all of it is
 // still dirty when the kernel ends and the end-of-kernel release has to flush it (measured: WT wins up
 // to ~4096 columns, loses beyond ~16k).  SPC_FORCE_WT=0/1 overrides (A/B runs).
-int small_batch(int64_t bytes_written)
+int wt_forced()      // SPC_FORCE_WT: 0 / 1, else -1
 {
-    static const int forced = [] { const char *e = getenv("SPC_FORCE_WT"); return e ? atoi(e) : -1; }();
-    if (forced == 0 || forced == 1) return forced;
-    return bytes_written <= (int64_t)32 * 1024 * 1024 ? 1 : 0;
+    static const int forced = [] { const char *e = getenv("SPC_FORCE_WT"); const int v = e ? atoi(e) : -1; return v == 0 || v == 1 ? v : -1; }();
+    return forced;
+}
+
+int small_batch(int64_t bytes_written, int limit_mib = 32)
+{
+    if (wt_forced() >= 0) return wt_forced();
+    return bytes_written <= (int64_t)limit_mib * 1024 * 1024 ? 1 : 0;
 }
 
 // 0 = generic; 1..3 = compile-time geometries with contiguous columns (see k_forward)
@@ -1277,7 +1293,9 @@ template <typename T> int choose_bwd(const spc_dims *d, bool cons, Choice *c)
 {
     c->kernel = cons ? "k_backward_cons2" : "k_backward"; c->elem = (int)sizeof(T); c->full = cons; c->idx = 0;
     c->geo = geometry_id(d);
-    c->wt = cons ? 0 : small_batch(d->n_cols * (int64_t)(7 * d->nG * sizeof(T)));
+    // K3's stores stop gaining from write-through earlier than K1's: at 2 560 columns (13 MB written) it still wins 5-7 %, at
+    // 3 072 ... 6 144 it loses 2-5 % (profiles/r04_write_through_sweep.log); K4 loses 10 % at config 3 (182 MB)
+    c->wt = cons ? 0 : small_batch(d->n_cols * (int64_t)(7 * d->nG * sizeof(T)), 14);
     const int sb = (cons || !c->wt) ? 0 : small_block(d, d->nL > d->nG ? d->nL : d->nG);
     const int pre_env = env_int("SPC_K3_PRE", -1);        // SPC_K3_PRE=0/1 forces the prologue prefetch off / on (A/B)
     // PRE = false (8 waves per SIMD) pays between one round of workgroups and saturation: 1 025 ... 25 000 columns

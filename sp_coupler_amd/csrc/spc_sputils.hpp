@@ -80,7 +80,28 @@ template <typename T> __device__ __forceinline__ T *su_at(T *base, int off)
     return (T *)((char *)base + (unsigned)(off * (int)sizeof(T)));
 }
 
-// (su_pad / su_count -- the fixed-trip searches on NaN-padded LDS rows -- live in spc_hip.hip: K4 uses them too)
+// r * pitch for a slab row r < 64 and a pitch below 2^24 elements (su_pitch_ok): the full-rate 24-bit multiply -- a
+// v_mul_lo_u32 occupies the SIMD four times as long, and the standalone operators are bound by VALU issue
+__device__ __forceinline__ int su_mul(int r, int pitch) { return (int)__umul24((unsigned)r, (unsigned)pitch); }
+
+// The (row, entry) of a thread's outputs: output e = tid + k * SU_THREADS of a slab of rows with n entries each.  The step
+// between two outputs of a thread is the same for all threads -- (dr, di) = divmod(SU_THREADS, n) plus one carry -- so no
+// division and no loop per output.
+struct SuWalk {
+    int r, i, n, dr, di;
+    __device__ __forceinline__ SuWalk(int tid, int n_) : n(n_)
+    {
+        r = tid / n; i = tid - r * n;
+        dr = SU_THREADS / n; di = SU_THREADS - dr * n;
+    }
+    __device__ __forceinline__ void next()
+    {
+        i += di; r += dr;
+        if (i >= n) { i -= n; ++r; }
+    }
+};
+
+// (su_pad / su_seek / su_count -- the fixed-trip searches on NaN-padded LDS rows -- live in spc_hip.hip: K4 uses them too)
 
 // nrow rows of n elements (row r at src + r * pitch) into LDS rows of `stride` entries, the tail of every row NaN;
 // U entries of a thread in flight before its first LDS store; (row, entry) stepped, never divided
@@ -103,36 +124,30 @@ template <int U, typename T> __device__ __forceinline__ void su_stage_rows(T *ds
     }
 }
 
-// numpy.interp's bracket (as bracket()) on a padded LDS row
-template <int SL, typename T> __device__ __forceinline__ Bracket<T> bracket_pad(const T *xp, int n, int p2, T x)
+// numpy.interp at one point x on a staged row: xp NaN-padded for su_seek, fp alongside.  The standalone interp is bound
+// by VALU issue (K1 / K3, which are not, keep bracket() / lerp_np as they are), so the common case -- x inside the
+// table -- runs straight through: clamp the cell, read its four corners, one IEEE division, and SELECT the end values
+// (x < xp[0] -> fp[0]; x >= xp[n-1] -> fp[n-1]; x == xp[j] -> fp[j]: numpy's own order of tests); NaN (a NaN x, or numpy's
+// fallbacks for a non-finite product) is a rare branch.
+template <int SL, typename T> __device__ __forceinline__ T su_interp_pad(const T *xp, const T *fp, int n, int p2, T x)
 {
-    Bracket<T> b;
-    b.x = x;
-    if (n == 1) { b.mode = 1; b.j = 0; b.x0 = b.x1 = x; return b; }   // numpy lenxp == 1: fp[0], NaN x included
-    if (x != x) { b.mode = 2; b.j = 0; b.x0 = b.x1 = x; return b; }
-    const int j = su_count<SL>(xp, p2, [&](T e) { return e <= x; }) - 1;
-    if (j < 0) { b.mode = 1; b.j = 0; b.x0 = b.x1 = x; return b; }                  // x < xp[0] -> fp[0]
-    if (j >= n - 1) { b.mode = 1; b.j = n - 1; b.x0 = b.x1 = x; return b; }         // x >= xp[n-1] -> fp[n-1]
-    b.j = j;
-    b.x0 = xp[j];
-    b.x1 = xp[j + 1];
-    b.mode = (b.x0 == x) ? 1 : 0;                                                   // exact hit -> fp[j]
-    return b;
-}
-
-// interp_at() with numpy's NaN fallbacks kept as a (rare) branch instead of being computed for every lane and selected:
-// the standalone interp is bound by VALU issue (K1 / K3, which are not, keep lerp_np as it is)
-template <typename T> __device__ __forceinline__ T su_interp_at(const Bracket<T> &b, const T *fp)
-{
-    if (b.mode == 2) return b.x;
-    if (b.mode == 1) return fp[b.j];
-    const T f0 = fp[b.j], f1 = fp[b.j + 1];
-    const T slope = (f1 - f0) / (b.x1 - b.x0);
-    T r = slope * (b.x - b.x0) + f0;
-    if (__builtin_expect(r != r, 0)) {
-        r = slope * (b.x - b.x1) + f1;
+    if (n == 1) return fp[0];                                                       // numpy lenxp == 1: fp[0], NaN x included
+    const T *const e = su_seek<SL>(xp, p2, [&](T v) { return v <= x; });           // first entry > x (or the NaN padding)
+    const int cnt = (int)(((unsigned)(size_t)e - (unsigned)(size_t)xp) / (unsigned)sizeof(T));   // entries <= x
+    int j = cnt - 1;
+    j = j < 0 ? 0 : j;
+    j = j > n - 2 ? n - 2 : j;
+    const T x0 = xp[j], x1 = xp[j + 1], f0 = fp[j], f1 = fp[j + 1];
+    const T slope = (f1 - f0) / (x1 - x0);
+    T r = slope * (x - x0) + f0;
+    const bool low = cnt == 0 || x0 == x, high = cnt >= n;
+    if (__builtin_expect(r != r && !low && !high, 0)) {                              // numpy's fallbacks, in its order
+        r = slope * (x - x1) + f1;
         if (r != r && f0 == f1) r = f0;
     }
+    r = low ? f0 : r;
+    r = high ? f1 : r;
+    if (__builtin_expect(x != x, 0)) r = x;                                          // a NaN x counts nothing: numpy returns it
     return r;
 }
 
@@ -176,31 +191,35 @@ template <typename T, int SL, int WT> __global__ __launch_bounds__(SU_THREADS) v
     const T *const xg = (const T *)q.x, *const xpg = (const T *)q.xp, *const fpg = (const T *)q.fp;
     T *const out = (T *)q.out;
     T *const lfp = lds, *const lxp = lds + (size_t)q.rb * n_xp;
+    // addresses: the slab's (uniform) base + a 32-bit element offset r * pitch + i (the host keeps rb * pitch below 2^31)
+    const T *const xb = xg + row0 * q.pitch_x;
+    T *const ob = out + row0 * q.pitch_out;
+    const int px = (int)q.pitch_x, po = (int)q.pitch_out;
+    const int cnt = nrow * n_x;
+    SuWalk w(tid, n_x);                                       // (row, point) of this thread's outputs
+    // a thread's x values are loaded one output AHEAD (the first before the staging): the load's latency sits behind the
+    // evaluation of the previous output instead of in front of every search
+    T xn = tid < cnt ? ldg(su_at(xb, su_mul(w.r, px) + w.i)) : T(0);
     if constexpr (STAGE) {
         su_stage<3>(lfp, nrow * n_xp, tid, su_slab<T>(q.fp, row0, q.pitch_fp, n_xp));
         if (q.pitch_xp) su_stage_rows<3>(lxp, nrow, n_xp, stride, tid, xpg + row0 * q.pitch_xp, (int)q.pitch_xp);
         else su_stage_rows<2>(lxp, 1, n_xp, stride, tid, xpg, 0);
         __syncthreads();
     }
-    // addresses: the slab's (uniform) base + a 32-bit element offset r * pitch + i (the host keeps rb * pitch below 2^31)
-    const T *const xb = xg + row0 * q.pitch_x;
-    T *const ob = out + row0 * q.pitch_out;
-    const int px = (int)q.pitch_x, po = (int)q.pitch_out;
-    const int cnt = nrow * n_x;
-    int r = tid / n_x, i = tid - r * n_x;                     // (row, point) of this thread's first output; then stepped
     for (int e = tid; e < cnt; e += SU_THREADS) {
-        const int64_t row = row0 + r;
-        const T xv = ldg(su_at(xb, r * px + i));
+        const int r = w.r, i = w.i;
+        const T xv = xn;
+        w.next();
+        if (e + SU_THREADS < cnt) xn = ldg(su_at(xb, su_mul(w.r, px) + w.i));
         T res;
         if constexpr (STAGE) {
-            const T *const xpr = q.pitch_xp ? lxp + (size_t)r * stride : lxp;
-            res = su_interp_at(bracket_pad<SL>(xpr, n_xp, q.p2, xv), lfp + (size_t)r * n_xp);
+            const T *const xpr = q.pitch_xp ? lxp + su_mul(r, stride) : lxp;
+            res = su_interp_pad<SL>(xpr, lfp + su_mul(r, n_xp), n_xp, q.p2, xv);
         } else {
+            const int64_t row = row0 + r;
             res = interp_at(bracket(xpg + row * q.pitch_xp, n_xp, q.p2, xv), fpg + row * q.pitch_fp);
         }
-        stg<WT>(su_at(ob, r * po + i), res);
-        i += SU_THREADS;
-        while (i >= n_x) { i -= n_x; ++r; }
+        stg<WT>(su_at(ob, su_mul(r, po) + i), res);
     }
 }
 
@@ -231,34 +250,35 @@ template <typename T, int SL, int WT> __global__ __launch_bounds__(SU_THREADS) v
     const int nrow = (int)((q.n_rows - row0) < q.rb ? (q.n_rows - row0) : q.rb);
     const T *const ag = (const T *)q.a, *const vg = (const T *)q.v;
     const int n_a = q.n_a, n_v = q.n_v, tid = threadIdx.x, stride = su_pad(q.p2);
+    const T *const vb = vg + row0 * q.pitch_v;
+    int64_t *const ob = q.out + row0 * q.pitch_out;
+    const int pv = (int)q.pitch_v, po = (int)q.pitch_out;
+    const int cnt = nrow * n_v;
+    SuWalk w(tid, n_v);
+    T kn = tid < cnt ? ldg(su_at(vb, su_mul(w.r, pv) + w.i)) : T(0);      // keys one output ahead, as k_interp's x
     if constexpr (STAGE) {
         if (q.pitch_a) su_stage_rows<3>(lds, nrow, n_a, stride, tid, ag + row0 * q.pitch_a, (int)q.pitch_a);
         else su_stage_rows<2>(lds, 1, n_a, stride, tid, ag, 0);
         __syncthreads();
     }
-    const T *const vb = vg + row0 * q.pitch_v;
-    int64_t *const ob = q.out + row0 * q.pitch_out;
-    const int pv = (int)q.pitch_v, po = (int)q.pitch_out;
-    const int cnt = nrow * n_v;
-    int r = tid / n_v, i = tid - r * n_v;
     for (int e = tid; e < cnt; e += SU_THREADS) {
-        const int64_t row = row0 + r;
-        const T key = ldg(su_at(vb, r * pv + i));
+        const int r = w.r, i = w.i;
+        const T key = kn;
+        w.next();
+        if (e + SU_THREADS < cnt) kn = ldg(su_at(vb, su_mul(w.r, pv) + w.i));
         int idx;
         if constexpr (STAGE) {
             // the insertion point of a sorted row = the number of entries in front of it: side='right' those with
             // !(key < a[i]), side='left' those with a[i] < key, in numpy's NaN-last order (np_lt); a NaN key passes the
             // NaN padding too, hence the clamp
-            const T *const ar = q.pitch_a ? lds + (size_t)r * stride : lds;
+            const T *const ar = q.pitch_a ? lds + su_mul(r, stride) : lds;
             idx = q.right ? su_count<SL>(ar, q.p2, [&](T a) { return !np_lt(key, a); }) : su_count<SL>(ar, q.p2, [&](T a) { return np_lt(a, key); });
             idx = idx < n_a ? idx : n_a;
         } else {
-            const T *const ar = ag + row * q.pitch_a;
+            const T *const ar = ag + (row0 + r) * q.pitch_a;
             idx = q.right ? ss_right(ar, n_a, key) : ss_left(ar, n_a, key);
         }
-        stg<WT>(su_at(ob, r * po + i), (int64_t)idx);
-        i += SU_THREADS;
-        while (i >= n_v) { i -= n_v; ++r; }
+        stg<WT>(su_at(ob, su_mul(r, po) + i), (int64_t)idx);
     }
 }
 
@@ -306,6 +326,13 @@ template <typename T, int PD, int SL, bool WEIGHTED, int WT> __global__ __launch
     // LDS: tn[rb][nc] | td[rb][nc] (WEIGHTED) | z rows padded for su_count ([rb] of them, or one when zh is shared)
     T *const ltn = lds, *const ltd = lds + (size_t)p.rb * nc, *const lz = ltd + (WEIGHTED ? (size_t)p.rb * nc : 0);
     const T *const qb = qg + row0 * p.pitch_q, *const wb = wg + row0 * p.pitch_q, *const zb = zg + row0 * p.pitch_zh;    // slab bases
+    const T *const Zb = (const T *)p.Zh + row0 * p.pitch_Zh;
+    T *const ob = (T *)p.out + row0 * p.pitch_out;
+    const int cnt_out = nrow * nG;
+    SuWalk w(tid, nG);
+    // a layer's two bounds are loaded one output ahead (the first pair before the staging), as k_interp's x
+    T topn = T(0), botn = T(0);
+    if (tid < cnt_out) { const int oZ = su_mul(w.r, (int)p.pitch_Zh) + w.i; topn = ldg(su_at(Zb, oZ)); botn = ldg(su_at(Zb, oZ + 1)); }
     if constexpr (STAGE) {
         const int total = nrow * nc;
         int r0 = tid / nc, l0 = tid - r0 * nc;                 // (row, cell) of element e0; stepped, not divided
@@ -339,15 +366,12 @@ template <typename T, int PD, int SL, bool WEIGHTED, int WT> __global__ __launch
         else su_stage_rows<2>(lz, 1, nL, zstride, tid, zg, 0);
         __syncthreads();
     }
-    const T *const Zb = (const T *)p.Zh + row0 * p.pitch_Zh;
-    T *const ob = (T *)p.out + row0 * p.pitch_out;
-    const int cnt_out = nrow * nG;
-    int r = tid / nG, k = tid - r * nG;
     for (int e = tid; e < cnt_out; e += SU_THREADS) {
-        const int64_t row = row0 + r;
-        const T *const z = STAGE ? lz + (p.pitch_zh ? (size_t)r * zstride : 0) : zg + row * p.pitch_zh;
-        const int oZ = r * (int)p.pitch_Zh + k;
-        const T top = ldg(su_at(Zb, oZ)), bot = ldg(su_at(Zb, oZ + 1));
+        const int r = w.r, k = w.i;
+        const T top = topn, bot = botn;
+        w.next();
+        if (e + SU_THREADS < cnt_out) { const int oZ = su_mul(w.r, (int)p.pitch_Zh) + w.i; topn = ldg(su_at(Zb, oZ)); botn = ldg(su_at(Zb, oZ + 1)); }
+        const T *const z = STAGE ? lz + (p.pitch_zh ? su_mul(r, zstride) : 0) : zg + (row0 + r) * p.pitch_zh;
         T res = T(0);                                                                  // Q = zeros / RHO = zeros
         if (p.mode == SU_INTEGRAL || top < z[nL - 1]) {                                // sputils.py:187 / 195
             T a = bot, b = top;                                                        // integral(ZZ[i+1], ZZ[i], ...)
@@ -369,14 +393,14 @@ template <typename T, int PD, int SL, bool WEIGHTED, int WT> __global__ __launch
                 if (ib < ia) ib = ia;
                 const int cnt = ib - ia + 1;
                 const T da = a - z[ia], db = z[ib + 1] - b;
-                const T *const qr = qb + r * (int)p.pitch_q, *const wr = wb + r * (int)p.pitch_q;
+                const T *const qr = qb + su_mul(r, (int)p.pitch_q), *const wr = wb + su_mul(r, (int)p.pitch_q);
                 const T qa = ldg(qr + ia), qe = ldg(qr + ib);
                 T num, den = T(1);
                 if constexpr (WEIGHTED) {
                     const T wa = ldg(wr + ia), we = ldg(wr + ib);
                     Pair2<T> S;
                     if constexpr (STAGE) {
-                        const T *const tn = ltn + (size_t)r * nc + ia, *const td = ltd + (size_t)r * nc + ia;
+                        const T *const tn = ltn + su_mul(r, nc) + ia, *const td = ltd + su_mul(r, nc) + ia;
                         S = su_npsum<PD>([&](int i) { return Pair2<T>(tn[i], td[i]); }, cnt);
                     } else {
                         S = su_npsum<PD>([&](int i) {
@@ -389,7 +413,7 @@ template <typename T, int PD, int SL, bool WEIGHTED, int WT> __global__ __launch
                 } else {
                     T S;
                     if constexpr (STAGE) {
-                        const T *const tn = ltn + (size_t)r * nc + ia;
+                        const T *const tn = ltn + su_mul(r, nc) + ia;
                         S = su_npsum<PD>([&](int i) { return tn[i]; }, cnt);
                     } else {
                         S = su_npsum<PD>([&](int i) { return qr[ia + i] * (z[ia + i + 1] - z[ia + i]); }, cnt);
@@ -400,9 +424,7 @@ template <typename T, int PD, int SL, bool WEIGHTED, int WT> __global__ __launch
                 if (p.mode == SU_INTERP_RHO) res = res / (top - bot);                   // sputils.py:196
             }
         }
-        stg<WT>(su_at(ob, r * (int)p.pitch_out + k), res);
-        k += SU_THREADS;
-        while (k >= nG) { k -= nG; ++r; }
+        stg<WT>(su_at(ob, su_mul(r, (int)p.pitch_out) + k), res);
     }
 }
 

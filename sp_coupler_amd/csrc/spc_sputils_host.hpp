@@ -3,8 +3,16 @@
 #pragma once
 
 // ---- host side ----------------------------------------------------------------------------------
-// write-through stores for launches that leave <= 32 MiB behind (small_batch, as K1 / K3)
-#define SU_PICK_WT(KERN_WT1, KERN_WT0, bytes) (small_batch((int64_t)(bytes)) ? (KERN_WT1) : (KERN_WT0))
+// Write-through stores for launches that leave <= 64 MiB behind.  (K1 / K3's small_batch() draws that line at the 32 MiB of
+// the aggregate L2; measured on these operators -- profiles/r04_write_through_sweep.log -- write-through still wins at the
+// 45.7 MB interp GCM->LES writes at 35 718 rows: 20.8 against 23.7 us, the dirty lines otherwise wait for the end-of-kernel
+// release.)  SPC_FORCE_WT=0/1 overrides as for K1 / K3.
+inline int su_write_through(int64_t bytes_written)
+{
+    if (wt_forced() >= 0) return wt_forced();
+    return bytes_written <= (int64_t)64 * 1024 * 1024 ? 1 : 0;
+}
+#define SU_PICK_WT(KERN_WT1, KERN_WT0, bytes) (su_write_through((int64_t)(bytes)) ? (KERN_WT1) : (KERN_WT0))
 
 template <typename T> int exner_impl(int64_t n, const void *p, void *out, int inverse, void *stream)
 {
@@ -30,14 +38,28 @@ inline int su_rows(int64_t n_rows, int n_out, size_t lds_per_row, size_t lds_fix
     const int64_t most = n_rows / 1024;                     // >= 1024 workgroups = 4 per CU
     if (rb > most) rb = most < 1 ? 1 : (int)most;
     while (rb > 1 && (lds_per_row * rb + lds_fixed) * esize > (size_t)16 * 1024) --rb;      // 16 KiB: >= 8 workgroups per CU
+    // every wave of a workgroup runs ceil(rb n_out / 256) rounds of the output loop, the last one partly idle: among the
+    // slab heights within two rows of that choice take the one that wastes the fewest lane-rounds (91 -> 160 levels: 8 rows =
+    // exactly 5 rounds instead of 7 rows = 4.4 rounds paid as 5; the operators are bound by VALU issue)
+    static const bool fit = [] { const char *e = getenv("SPC_SU_FIT"); return !e || atoi(e) != 0; }();
+    if (fit && n_out > 0) {
+        auto waste = [&](int c) { const int64_t o = (int64_t)c * n_out, rounds = (o + SU_THREADS - 1) / SU_THREADS; return (double)(rounds * SU_THREADS - o) / (double)(rounds * SU_THREADS); };
+        int best = rb;
+        for (int c = rb > 2 ? rb - 2 : 1; c <= rb + 2 && c <= 64; ++c) {
+            if (c > most && c > 1) break;
+            if ((lds_per_row * c + lds_fixed) * esize > (size_t)16 * 1024 && c > rb) break;
+            if (waste(c) < waste(best) - 0.02) best = c;
+        }
+        rb = best;
+    }
     *stage = (lds_per_row * rb + lds_fixed) * esize <= SU_MAX_LDS;
     return rb;
 }
 
-// the kernels address a slab with 32-bit element offsets r * pitch + i (r < 64 rows): pitches stay below 2^24 elements
+// the kernels address a slab with 32-bit element offsets r * pitch + i (r < 64 rows, 24-bit multiply): pitches stay below 2^24 elements
 inline bool su_pitch_ok(std::initializer_list<int64_t> pitches)
 {
-    for (int64_t p : pitches) if (p > ((int64_t)1 << 24)) return false;
+    for (int64_t p : pitches) if (p >= ((int64_t)1 << 24)) return false;
     return true;
 }
 
@@ -78,7 +100,7 @@ template <typename T> int interp_impl(const spc_interp_args *a, void *stream)
     REQUIRE(a->x, "x"); REQUIRE(a->xp, "xp"); REQUIRE(a->fp, "fp"); REQUIRE(a->out, "out");
     if ((a->pitch_x && a->pitch_x < a->n_x) || (a->pitch_xp && a->pitch_xp < a->n_xp) || a->pitch_fp < a->n_xp || a->pitch_out < a->n_x)
         return fail(SPC_ERR_INVALID_ARGUMENT, "%sinterp: a pitch is smaller than its row (only x and xp may be shared, pitch 0)");
-    if (!su_pitch_ok({a->pitch_x, a->pitch_xp, a->pitch_fp, a->pitch_out})) return fail(SPC_ERR_UNSUPPORTED, "%sinterp: a row pitch beyond 2^24 elements");
+    if (!su_pitch_ok({a->pitch_x, a->pitch_xp, a->pitch_fp, a->pitch_out})) return fail(SPC_ERR_UNSUPPORTED, "%sinterp: a row pitch of 2^24 elements or more");
     SuInterpP q;
     q.n_rows = a->n_rows; q.pitch_x = a->pitch_x; q.pitch_xp = a->pitch_xp; q.pitch_fp = a->pitch_fp; q.pitch_out = a->pitch_out;
     q.n_x = a->n_x; q.n_xp = a->n_xp; q.p2 = floor_pow2(a->n_xp);
@@ -91,7 +113,7 @@ template <typename T> int interp_impl(const spc_interp_args *a, void *stream)
     const size_t smem = stage ? (per_row * q.rb + fixed) * sizeof(T) : 0;
     const int64_t wr = a->n_rows * (int64_t)a->n_x * (int64_t)sizeof(T);
     const int sl = stage ? su_sl(q.p2) : -1;
-    void (*kern)(const SuInterpP) = small_batch(wr) ? interp_kernel<T, 1>(sl) : interp_kernel<T, 0>(sl);
+    void (*kern)(const SuInterpP) = su_write_through(wr) ? interp_kernel<T, 1>(sl) : interp_kernel<T, 0>(sl);
     hipLaunchKernelGGL(kern, dim3((unsigned)((a->n_rows + q.rb - 1) / q.rb)), dim3(SU_THREADS), smem, (hipStream_t)stream, q);
     return launch_status("k_interp");
 }
@@ -105,7 +127,7 @@ template <typename T> int searchsorted_impl(const spc_searchsorted_args *a, void
     if (a->n_a) REQUIRE(a->a, "a");
     if ((a->pitch_a && a->pitch_a < a->n_a) || (a->pitch_v && a->pitch_v < a->n_v) || a->pitch_out < a->n_v)
         return fail(SPC_ERR_INVALID_ARGUMENT, "%ssearchsorted: a pitch is smaller than its row (only a and v may be shared, pitch 0)");
-    if (!su_pitch_ok({a->pitch_a, a->pitch_v, a->pitch_out})) return fail(SPC_ERR_UNSUPPORTED, "%ssearchsorted: a row pitch beyond 2^24 elements");
+    if (!su_pitch_ok({a->pitch_a, a->pitch_v, a->pitch_out})) return fail(SPC_ERR_UNSUPPORTED, "%ssearchsorted: a row pitch of 2^24 elements or more");
     SuSearchP q;
     q.n_rows = a->n_rows; q.pitch_a = a->pitch_a; q.pitch_v = a->pitch_v; q.pitch_out = a->pitch_out;
     q.n_a = a->n_a; q.n_v = a->n_v; q.right = a->side_right != 0; q.p2 = floor_pow2(a->n_a);
@@ -117,7 +139,7 @@ template <typename T> int searchsorted_impl(const spc_searchsorted_args *a, void
     const size_t smem = stage ? ((a->pitch_a ? arow : 0) * q.rb + (a->pitch_a ? 0 : arow)) * sizeof(T) : 0;
     const int64_t wr = a->n_rows * (int64_t)a->n_v * 8;
     const int sl = stage ? su_sl(q.p2) : -1;
-    void (*kern)(const SuSearchP) = small_batch(wr) ? searchsorted_kernel<T, 1>(sl) : searchsorted_kernel<T, 0>(sl);
+    void (*kern)(const SuSearchP) = su_write_through(wr) ? searchsorted_kernel<T, 1>(sl) : searchsorted_kernel<T, 0>(sl);
     hipLaunchKernelGGL(kern, dim3((unsigned)((a->n_rows + q.rb - 1) / q.rb)), dim3(SU_THREADS), smem, (hipStream_t)stream, q);
     return launch_status("k_searchsorted");
 }
@@ -155,7 +177,7 @@ template <typename T> int interp_c_impl(const spc_interp_c_args *a, void *stream
     if (a->n_rows > 0x7fffffff) return fail(SPC_ERR_UNSUPPORTED, "%sinterp_c: more than 2^31-1 rows");
     if (a->pitch_Zh < a->nG + 1 || (a->pitch_zh && a->pitch_zh < a->nL) || a->pitch_q < a->nL - 1 || a->pitch_out < a->nG)
         return fail(SPC_ERR_INVALID_ARGUMENT, "%sinterp_c: a pitch is smaller than its row (only zh may be shared, pitch 0)");
-    if (!su_pitch_ok({a->pitch_Zh, a->pitch_zh, a->pitch_q, a->pitch_out})) return fail(SPC_ERR_UNSUPPORTED, "%sinterp_c: a row pitch beyond 2^24 elements");
+    if (!su_pitch_ok({a->pitch_Zh, a->pitch_zh, a->pitch_q, a->pitch_out})) return fail(SPC_ERR_UNSUPPORTED, "%sinterp_c: a row pitch of 2^24 elements or more");
     SuCoarseP q;
     q.n_rows = a->n_rows; q.pitch_Zh = a->pitch_Zh; q.pitch_zh = a->pitch_zh; q.pitch_q = a->pitch_q; q.pitch_out = a->pitch_out;
     q.nG = a->nG; q.nL = a->nL; q.mode = a->mode;
@@ -171,7 +193,7 @@ template <typename T> int interp_c_impl(const spc_interp_c_args *a, void *stream
     // numpy's pairwise recursion unrolled to the depth a layer of <= nL - 1 cells needs (cons_depth, as K4); the float twin
     // and grids of more than 1024 points keep the explicit stack
     const int pd = sizeof(T) == 8 ? cons_depth(a->nL) : -1;
-    const bool wt = small_batch(a->n_rows * (int64_t)a->nG * (int64_t)sizeof(T)) != 0;
+    const bool wt = su_write_through(a->n_rows * (int64_t)a->nG * (int64_t)sizeof(T)) != 0;
     const int sl = stage ? su_sl(q.p2) : -1;
     void (*kern)(const SuCoarseP) = weighted ? (wt ? interp_c_kernel_sl<T, true, 1>(sl, pd) : interp_c_kernel_sl<T, true, 0>(sl, pd))
                                              : (wt ? interp_c_kernel_sl<T, false, 1>(sl, pd) : interp_c_kernel_sl<T, false, 0>(sl, pd));

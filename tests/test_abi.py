@@ -109,6 +109,8 @@ def test_describe_launch_names_the_instantiation_the_launcher_would_pick(lib):
     assert k1(1024, nG=137, nL=512) == "k_forward<f64,lean,137,512,wt=1,blk=256,pre=1>"
     assert k3(1024) == "k_backward<f64,91,160,wt=1,blk=1024,pre=1>"
     assert k3(1025) == "k_backward<f64,91,160,wt=1,blk=256,pre=0>"
+    assert k3(2880) == "k_backward<f64,91,160,wt=1,blk=256,pre=0>"            # K3 stores write-through up to 14 MiB written
+    assert k3(2881) == "k_backward<f64,91,160,wt=0,blk=256,pre=0>"
     assert k3(25000) == "k_backward<f64,91,160,wt=0,blk=256,pre=0>"
     assert k3(25001) == "k_backward<f64,91,160,wt=0,blk=256,pre=1>"
     assert k3(4096, nG=19) == "k_backward<f64,19,160,wt=1,blk=256,pre=0>"

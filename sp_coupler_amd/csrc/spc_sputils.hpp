@@ -33,42 +33,6 @@
 constexpr int SU_THREADS = 256;
 constexpr size_t SU_MAX_LDS = 64 * 1024;
 
-// ---- staging: cnt elements, element e from at(e), into LDS dst[e]; U loads of a thread in flight before its first store --
-template <int U, typename T, typename At> __device__ __forceinline__ void su_stage(T *dst, int cnt, int tid, const At &at)
-{
-    for (int e0 = tid; e0 < cnt; e0 += SU_THREADS * U) {
-        T v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int e = e0 + u * SU_THREADS;
-            v[u] = e < cnt ? at(e) : T(0);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int e = e0 + u * SU_THREADS;
-            if (e < cnt) dst[e] = v[u];
-        }
-    }
-}
-
-// element e of the [nrow x n] slab that starts at row0: flat when the rows are contiguous (pitch == n), else by (row, j)
-template <typename T> struct SuSlab {
-    const T *base;     // row0's first element
-    int64_t pitch;
-    int n;
-    bool flat;
-    __device__ __forceinline__ T operator()(int e) const
-    {
-        if (flat) return ldg(base + e);
-        const int r = e / n, j = e - r * n;
-        return ldg(base + (r * (int)pitch + j));
-    }
-};
-template <typename T> __device__ __forceinline__ SuSlab<T> su_slab(const void *p, int64_t row0, int64_t pitch, int n)
-{
-    return SuSlab<T>{(const T *)p + row0 * pitch, pitch, n, pitch == (int64_t)n};
-}
-
 // element `off` (a 32-bit count off a wave-uniform base) addressed as base + zero-extended BYTE offset: the form the
 // backend turns into one global_load / global_store with a scalar base and a 32-bit VGPR offset (no 64-bit VALU arithmetic)
 template <typename T> __device__ __forceinline__ const T *su_at(const T *base, int off)
@@ -91,7 +55,10 @@ struct SuWalk {
     int r, i, n, dr, di;
     __device__ __forceinline__ SuWalk(int tid, int n_) : n(n_)
     {
-        r = tid / n; i = tid - r * n;
+        // tid / n for tid < 256 without a vector division: (tid * ceil(2^16 / n)) >> 16 is exact while 255 n < 2^16
+        const int m = (65536 + n - 1) / n;                       // uniform
+        r = n < SU_THREADS ? (int)(__umul24((unsigned)tid, (unsigned)m) >> 16) : (tid >= n ? 1 : 0);
+        i = tid - su_mul(r, n);
         dr = SU_THREADS / n; di = SU_THREADS - dr * n;
     }
     __device__ __forceinline__ void next()
@@ -101,6 +68,29 @@ struct SuWalk {
     }
 };
 
+// ---- staging: the [nrow x n] slab at `base` (rows `pitch` elements apart) into LDS dst[r * n + j]; U loads of a thread in
+// flight before its first store; flat when the rows are contiguous, else (row, entry) stepped
+template <int U, typename T> __device__ __forceinline__ void su_stage_slab(T *dst, int nrow, int n, int tid, const T *base, int pitch)
+{
+    const int cnt = nrow * n;
+    const bool flat = pitch == n;                             // uniform
+    SuWalk w(tid, n);
+    for (int e0 = tid; e0 < cnt; e0 += SU_THREADS * U) {
+        T v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * SU_THREADS;
+            v[u] = e < cnt ? ldg(su_at(base, flat ? e : su_mul(w.r, pitch) + w.i)) : T(0);
+            w.next();
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * SU_THREADS;
+            if (e < cnt) dst[e] = v[u];
+        }
+    }
+}
+
 // (su_pad / su_seek / su_count -- the fixed-trip searches on NaN-padded LDS rows -- live in spc_hip.hip: K4 uses them too)
 
 // nrow rows of n elements (row r at src + r * pitch) into LDS rows of `stride` entries, the tail of every row NaN;
@@ -109,14 +99,13 @@ template <int U, typename T> __device__ __forceinline__ void su_stage_rows(T *ds
 {
     const int total = nrow * stride;
     const T nan = T(0) / T(0);
-    int r = tid / stride, j = tid - r * stride;
+    SuWalk w(tid, stride);                                    // (row, entry) of LDS element t0 + u * SU_THREADS
     for (int t0 = tid; t0 < total; t0 += SU_THREADS * U) {
         T v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            v[u] = (t0 + u * SU_THREADS < total && j < n) ? ldg(su_at(src, r * pitch + j)) : nan;  // uniform base + 32-bit offset
-            j += SU_THREADS;
-            while (j >= stride) { j -= stride; ++r; }
+            v[u] = (t0 + u * SU_THREADS < total && w.i < n) ? ldg(su_at(src, su_mul(w.r, pitch) + w.i)) : nan;   // uniform base + 32-bit offset
+            w.next();
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -201,7 +190,7 @@ template <typename T, int SL, int WT> __global__ __launch_bounds__(SU_THREADS) v
     // evaluation of the previous output instead of in front of every search
     T xn = tid < cnt ? ldg(su_at(xb, su_mul(w.r, px) + w.i)) : T(0);
     if constexpr (STAGE) {
-        su_stage<3>(lfp, nrow * n_xp, tid, su_slab<T>(q.fp, row0, q.pitch_fp, n_xp));
+        su_stage_slab<3>(lfp, nrow, n_xp, tid, fpg + row0 * q.pitch_fp, (int)q.pitch_fp);
         if (q.pitch_xp) su_stage_rows<3>(lxp, nrow, n_xp, stride, tid, xpg + row0 * q.pitch_xp, (int)q.pitch_xp);
         else su_stage_rows<2>(lxp, 1, n_xp, stride, tid, xpg, 0);
         __syncthreads();
@@ -315,7 +304,10 @@ template <int PD, typename F> __device__ __forceinline__ auto su_npsum(const F &
 // LDS values in ndarray.sum() order (pairwise recursion unrolled to the depth PD the host derived from nL, as K4; PD = -1:
 // explicit stack).  The two edge pieces read q / w of the first and last cell from global memory (lines this workgroup has
 // just loaded).  STAGE = false (rows beyond the LDS): terms formed on the fly from global memory.
-template <typename T, int PD, int SL, bool WEIGHTED, int WT> __global__ __launch_bounds__(SU_THREADS) void k_interp_c(const SuCoarseP p)
+#ifndef SU_IC_WAVES      // waves per SIMD the register allocator is asked to fit: 5 = 96 VGPRs (15 spilled) runs 34 us at 35 718 rows,
+#define SU_IC_WAVES 5    // 4 (116 VGPRs, no spills) 36 us, 6 (80 VGPRs, 37 spilled) 38 us (profiles/r04_k7_slab_sweep.log)
+#endif
+template <typename T, int PD, int SL, bool WEIGHTED, int WT> __global__ __launch_bounds__(SU_THREADS, SU_IC_WAVES) void k_interp_c(const SuCoarseP p)
 {
     constexpr bool STAGE = SL >= 0;
     T *const lds = reinterpret_cast<T *>(spc_smem);
@@ -323,35 +315,35 @@ template <typename T, int PD, int SL, bool WEIGHTED, int WT> __global__ __launch
     const int nrow = (int)((p.n_rows - row0) < p.rb ? (p.n_rows - row0) : p.rb);
     const int nL = p.nL, nG = p.nG, nc = nL - 1, tid = threadIdx.x, zstride = su_pad(p.p2);     // nL points bound nc cells
     const T *const zg = (const T *)p.zh, *const qg = (const T *)p.q, *const wg = (const T *)p.rho;
-    // LDS: tn[rb][nc] | td[rb][nc] (WEIGHTED) | z rows padded for su_count ([rb] of them, or one when zh is shared)
-    T *const ltn = lds, *const ltd = lds + (size_t)p.rb * nc, *const lz = ltd + (WEIGHTED ? (size_t)p.rb * nc : 0);
+    // LDS: tn[rb][nc] | td[rb][nc] (WEIGHTED) | Zh[rb][nG+1] | out[rb][nG] | z rows padded for su_count ([rb] of them, or one
+    // when zh is shared)
+    T *const ltn = lds, *const ltd = lds + (size_t)p.rb * nc, *const lZ = ltd + (WEIGHTED ? (size_t)p.rb * nc : 0);
+    T *const lout = lZ + (size_t)p.rb * (nG + 1), *const lz = lout + (size_t)p.rb * nG;
     const T *const qb = qg + row0 * p.pitch_q, *const wb = wg + row0 * p.pitch_q, *const zb = zg + row0 * p.pitch_zh;    // slab bases
     const T *const Zb = (const T *)p.Zh + row0 * p.pitch_Zh;
     T *const ob = (T *)p.out + row0 * p.pitch_out;
     const int cnt_out = nrow * nG;
-    SuWalk w(tid, nG);
-    // a layer's two bounds are loaded one output ahead (the first pair before the staging), as k_interp's x
-    T topn = T(0), botn = T(0);
-    if (tid < cnt_out) { const int oZ = su_mul(w.r, (int)p.pitch_Zh) + w.i; topn = ldg(su_at(Zb, oZ)); botn = ldg(su_at(Zb, oZ + 1)); }
+    // Outputs are walked LAYER-major -- output e is layer e / nrow of row e % nrow -- so that a wave holds a few consecutive layers
+    // of all the slab's rows: the layers above the fine grid's top (most of them for interp_c on a column whose LES is shallow:
+    // sputils.py:187 leaves them zero) then fill WHOLE waves, which skip the integral, instead of idling in every wave.  The
+    // coarse levels Zh and the results go through LDS in their memory order (row-major, coalesced both ways).
+    SuWalk w(tid, nrow);                                      // w.r: the layer k, w.i: the row
     if constexpr (STAGE) {
         const int total = nrow * nc;
-        int r0 = tid / nc, l0 = tid - r0 * nc;                 // (row, cell) of element e0; stepped, not divided
+        SuWalk sw(tid, nc);                                    // (row, cell) of element e0 + u * SU_THREADS
         for (int e0 = tid; e0 < total; e0 += SU_THREADS * 2) {
             T qv[2], wv[2], z0[2], z1[2];
-            int rr = r0, ll = l0;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const bool in = e0 + u * SU_THREADS < total;
-                const int r = in ? rr : 0, l = in ? ll : 0;
-                const int o = r * (int)p.pitch_q + l, oz = r * (int)p.pitch_zh + l;      // 32-bit offsets off the slab's bases
+                const int r = in ? sw.r : 0, l = in ? sw.i : 0;
+                const int o = su_mul(r, (int)p.pitch_q) + l, oz = su_mul(r, (int)p.pitch_zh) + l;      // 32-bit offsets off the slab's bases
                 qv[u] = ldg(su_at(qb, o));
                 wv[u] = WEIGHTED ? ldg(su_at(wb, o)) : T(1);
                 z0[u] = ldg(su_at(zb, oz));
                 z1[u] = ldg(su_at(zb, oz + 1));
-                ll += SU_THREADS;
-                while (ll >= nc) { ll -= nc; ++rr; }
+                sw.next();
             }
-            r0 = rr; l0 = ll;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int e = e0 + u * SU_THREADS;
@@ -362,15 +354,16 @@ template <typename T, int PD, int SL, bool WEIGHTED, int WT> __global__ __launch
                 }
             }
         }
+        su_stage_slab<2>(lZ, nrow, nG + 1, tid, Zb, (int)p.pitch_Zh);
         if (p.pitch_zh) su_stage_rows<2>(lz, nrow, nL, zstride, tid, zb, (int)p.pitch_zh);
         else su_stage_rows<2>(lz, 1, nL, zstride, tid, zg, 0);
         __syncthreads();
     }
-    for (int e = tid; e < cnt_out; e += SU_THREADS) {
-        const int r = w.r, k = w.i;
-        const T top = topn, bot = botn;
-        w.next();
-        if (e + SU_THREADS < cnt_out) { const int oZ = su_mul(w.r, (int)p.pitch_Zh) + w.i; topn = ldg(su_at(Zb, oZ)); botn = ldg(su_at(Zb, oZ + 1)); }
+    for (int e = tid; e < cnt_out; e += SU_THREADS, w.next()) {
+        const int r = w.i, k = w.r;
+        T top, bot;
+        if constexpr (STAGE) { const T *const Zr = lZ + su_mul(r, nG + 1) + k; top = Zr[0]; bot = Zr[1]; }
+        else { const int oZ = su_mul(r, (int)p.pitch_Zh) + k; top = ldg(su_at(Zb, oZ)); bot = ldg(su_at(Zb, oZ + 1)); }
         const T *const z = STAGE ? lz + (p.pitch_zh ? su_mul(r, zstride) : 0) : zg + (row0 + r) * p.pitch_zh;
         T res = T(0);                                                                  // Q = zeros / RHO = zeros
         if (p.mode == SU_INTEGRAL || top < z[nL - 1]) {                                // sputils.py:187 / 195
@@ -424,7 +417,15 @@ template <typename T, int PD, int SL, bool WEIGHTED, int WT> __global__ __launch
                 if (p.mode == SU_INTERP_RHO) res = res / (top - bot);                   // sputils.py:196
             }
         }
-        stg<WT>(su_at(ob, su_mul(r, (int)p.pitch_out) + k), res);
+        if constexpr (STAGE) lout[su_mul(r, nG) + k] = res;
+        else stg<WT>(su_at(ob, su_mul(r, (int)p.pitch_out) + k), res);
+    }
+    if constexpr (STAGE) {                                    // the slab's results, row-major: whole lines per store instruction
+        __syncthreads();
+        SuWalk ow(tid, nG);
+        const bool flat = p.pitch_out == nG;
+        for (int e = tid; e < cnt_out; e += SU_THREADS, ow.next())
+            stg<WT>(su_at(ob, flat ? e : su_mul(ow.r, (int)p.pitch_out) + ow.i), lout[e]);
     }
 }
 

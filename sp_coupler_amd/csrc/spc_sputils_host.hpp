@@ -29,29 +29,33 @@ template <typename T> int exner_impl(int64_t n, const void *p, void *out, int in
 // Rows per workgroup (the slab): enough rows for ~`target` outputs per workgroup -- 4-5 per thread, the shape of K1's
 // 8-column slabs -- within the LDS budget, but never so many that the grid drops under four workgroups per CU (small
 // batches are latency-bound: more, smaller workgroups).  SPC_SU_TARGET overrides for A/B runs.
-inline int su_rows(int64_t n_rows, int n_out, size_t lds_per_row, size_t lds_fixed, size_t esize, int *stage)
+inline int su_rows(int64_t n_rows, int n_out, size_t lds_per_row, size_t lds_fixed, size_t esize, int *stage, int lds_kib = 16, bool fit_rounds = true)
 {
     static const int target = [] { const char *e = getenv("SPC_SU_TARGET"); const int v = e ? atoi(e) : 1100; return v < 1 ? 1 : v; }();
+    static const int cap_env = [] { const char *e = getenv("SPC_SU_LDS_KIB"); return e ? atoi(e) : 0; }();
+    const size_t cap = (size_t)(cap_env > 0 ? cap_env : lds_kib) * 1024;
     int rb = n_out > 0 ? (target + n_out - 1) / n_out : 1;
     if (rb < 1) rb = 1;
     if (rb > 64) rb = 64;
     const int64_t most = n_rows / 1024;                     // >= 1024 workgroups = 4 per CU
     if (rb > most) rb = most < 1 ? 1 : (int)most;
-    while (rb > 1 && (lds_per_row * rb + lds_fixed) * esize > (size_t)16 * 1024) --rb;      // 16 KiB: >= 8 workgroups per CU
+    while (rb > 1 && (lds_per_row * rb + lds_fixed) * esize > cap) --rb;      // 16 KiB: >= 8 workgroups per CU (SPC_SU_LDS_KIB: A/B runs)
     // every wave of a workgroup runs ceil(rb n_out / 256) rounds of the output loop, the last one partly idle: among the
     // slab heights within two rows of that choice take the one that wastes the fewest lane-rounds (91 -> 160 levels: 8 rows =
     // exactly 5 rounds instead of 7 rows = 4.4 rounds paid as 5; the operators are bound by VALU issue)
     static const bool fit = [] { const char *e = getenv("SPC_SU_FIT"); return !e || atoi(e) != 0; }();
-    if (fit && n_out > 0) {
+    if (fit && fit_rounds && n_out > 0) {
         auto waste = [&](int c) { const int64_t o = (int64_t)c * n_out, rounds = (o + SU_THREADS - 1) / SU_THREADS; return (double)(rounds * SU_THREADS - o) / (double)(rounds * SU_THREADS); };
         int best = rb;
         for (int c = rb > 2 ? rb - 2 : 1; c <= rb + 2 && c <= 64; ++c) {
             if (c > most && c > 1) break;
-            if ((lds_per_row * c + lds_fixed) * esize > (size_t)16 * 1024 && c > rb) break;
+            if ((lds_per_row * c + lds_fixed) * esize > cap && c > rb) break;
             if (waste(c) < waste(best) - 0.02) best = c;
         }
         rb = best;
     }
+    static const int forced = [] { const char *e = getenv("SPC_SU_RB"); return e ? atoi(e) : 0; }();      // A/B runs
+    if (forced > 0 && forced <= 64) rb = forced;
     *stage = (lds_per_row * rb + lds_fixed) * esize <= SU_MAX_LDS;
     return rb;
 }
@@ -184,11 +188,14 @@ template <typename T> int interp_c_impl(const spc_interp_c_args *a, void *stream
     q.Zh = a->Zh; q.zh = a->zh; q.q = a->q; q.rho = a->mode == SU_INTERP_RHO ? nullptr : a->rho; q.out = a->out;
     const bool weighted = q.rho != nullptr;
     q.p2 = floor_pow2(a->nL - 1);
-    // LDS per row: the cell terms tn (and td with weights) [nL - 1] + the row's padded grid unless the grid is shared
+    // LDS per row: the cell terms tn (and td with weights) [nL - 1], the coarse levels [nG + 1], the results [nG] + the row's
+    // padded grid unless the grid is shared
     const size_t zrow = (size_t)su_pad(q.p2);
-    const size_t per_row = (size_t)(a->nL - 1) * (weighted ? 2 : 1) + (a->pitch_zh ? zrow : 0), fixed = a->pitch_zh ? 0 : zrow;
+    const size_t per_row = (size_t)(a->nL - 1) * (weighted ? 2 : 1) + (size_t)(2 * a->nG + 1) + (a->pitch_zh ? zrow : 0), fixed = a->pitch_zh ? 0 : zrow;
     int stage;
-    q.rb = su_rows(a->n_rows, a->nG, per_row, fixed, sizeof(T), &stage);
+    // 32 KiB (five workgroups per CU, what the registers allow): the layer-major walk skips whole waves above the fine grid's top, the better the more rows a wave spans (measured
+    // at 35 718 rows: 5 rows 40.1 us, 7-9 rows 35.4-36.3, 12 rows 37.6: profiles/r04_k7_slab_sweep.log)
+    q.rb = su_rows(a->n_rows, a->nG, per_row, fixed, sizeof(T), &stage, 32, false);
     const size_t smem = stage ? (per_row * q.rb + fixed) * sizeof(T) : 0;
     // numpy's pairwise recursion unrolled to the depth a layer of <= nL - 1 cells needs (cons_depth, as K4); the float twin
     // and grids of more than 1024 points keep the explicit stack

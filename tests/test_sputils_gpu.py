@@ -343,3 +343,62 @@ def test_fuzz_random_shapes_sharing_and_pitches(sputils):
             want = numpy.stack([orc.interp_c(Zh[r], za if zsh else za[r], q[r], rho[r]) for r in range(n)])
         got = eng.interp_c(padded(numpy.ascontiguousarray(Zh)), padded(za), padded(q), padded(rho)).cpu().numpy()
         assert_bits("fuzz interp_c %d" % t, got, want)
+
+
+@pytest.mark.parametrize("seed,n", [(1, 5003), (2, 9001), (3, 14011)])
+def test_multi_row_slabs_equal_single_row_slabs(seed, n):
+    """The staged operators give a workgroup a SLAB of several rows once a launch has enough rows (>= 2 048; below that every
+    workgroup owns one row -- the shape all the oracle comparisons above run in; a slab has at most n_rows / 1024 rows, so 5 003 ...
+    14 011 rows reach slabs of 4 ... 13).  Row counts that leave a partial last slab, random lengths, shared or per-row sample arrays, padded pitches, NaN / inf / out-of-range points: the launch
+    over all rows must equal, bit for bit, the same rows launched 500 at a time (one row per workgroup, oracle-checked above)."""
+    from sp_coupler_amd import spcpl
+    eng = spcpl.get_engine()
+    rng = numpy.random.default_rng(900 + seed)
+
+    def dev(a, pad):
+        if a.ndim == 1 or not pad:
+            return torch.from_numpy(numpy.ascontiguousarray(a)).cuda()
+        buf = torch.full((a.shape[0], a.shape[1] + pad), float("nan"), dtype=torch.float64, device="cuda")
+        buf[:, :a.shape[1]] = torch.from_numpy(numpy.ascontiguousarray(a)).cuda()
+        return buf[:, :a.shape[1]]
+
+    def chunks(fn, *arrs):
+        """fn over rows [i, i + 500) of every 2-D argument (1-D ones are shared by all rows)"""
+        out = [fn(*[a if a.dim() == 1 else a[i:i + 500] for a in arrs]) for i in range(0, n, 500)]
+        return torch.cat(out).cpu().numpy()
+
+    def same(what, full, parts):
+        full = full.cpu().numpy()
+        assert full.shape == parts.shape, what
+        assert numpy.array_equal(full.view(numpy.int64) if full.dtype == numpy.float64 else full,
+                                 parts.view(numpy.int64) if parts.dtype == numpy.float64 else parts), what
+
+    for trial in range(4):
+        n_xp, n_x = int(rng.integers(2, 280)), int(rng.integers(1, 330))
+        xp = numpy.sort(rng.uniform(0, 1e4, size=(n, n_xp)), axis=1)
+        fp = rng.normal(size=(n, n_xp))
+        x = rng.uniform(-100, 1.01e4, size=(n, n_x))
+        x[:, 0] = xp[:, n_xp // 2]
+        x[7, n_x // 2], x[4999, 0], x[n - 1, n_x - 1] = numpy.nan, numpy.inf, -numpy.inf
+        xs, xps = rng.random() < 0.4, rng.random() < 0.4
+        pad = int(rng.integers(0, 6))
+        xd, xpd, fpd = dev(x[0] if xs else x, pad), dev(xp[0] if xps else xp, pad), dev(fp, pad)
+        same("interp %d" % trial, eng.interp(xd, xpd, fpd), chunks(eng.interp, xd, xpd, fpd))
+        for side in ("left", "right"):
+            f = lambda a, v: eng.searchsorted(a, v, side=side)    # noqa: E731
+            if not (xs and xps):
+                same("searchsorted %s %d" % (side, trial), f(xpd, xd), chunks(f, xpd, xd))
+        nL, nG = int(rng.integers(3, 300)), int(rng.integers(1, 120))
+        zh = numpy.cumsum(rng.uniform(0.5, 30, size=(n, nL)), axis=1)
+        zsh = rng.random() < 0.5
+        za = zh[0] if zsh else zh
+        top = (za[-1] if zsh else za[:, -1:]) * rng.uniform(0.6, 1.5, size=(n, 1))
+        bot = (za[0] if zsh else za[:, :1])
+        Zh = numpy.sort(rng.uniform(0, 1, size=(n, nG + 1)), axis=1)[:, ::-1] * (top - bot) + bot
+        Zh[:, -1] = bot if zsh else bot[:, 0]
+        Zh[11, nG // 2] = -3.0                                       # an end point below the grid: None -> NaN
+        q, rho = rng.normal(size=(n, nL)), rng.uniform(0.4, 1.3, size=(n, nL))
+        Zd, zd, qd, rd = dev(numpy.ascontiguousarray(Zh), pad), dev(za, pad), dev(q, pad), dev(rho, pad)
+        same("interp_c %d" % trial, eng.interp_c(Zd, zd, qd, rd), chunks(eng.interp_c, Zd, zd, qd, rd))
+        full = eng.interp_c(Zd, zd, qd, rd).cpu().numpy()
+        assert numpy.isnan(full[11]).any() and (full != 0).any() and (full == 0).any()

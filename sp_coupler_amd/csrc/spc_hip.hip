@@ -91,21 +91,33 @@ __device__ __forceinline__ double spc_pow(double x, double y) { return pow(x, y)
 // call: an out-of-line ocml pow() made every K1 wave reserve ITS 100 registers (4 waves per SIMD instead of 6).
 #define SPC_POW_FN __device__ __forceinline__
 #include "spc_pow.h"
+// C99 pow()'s value for an x outside (0, inf) and a non-integer y
+__device__ __forceinline__ double spc_pow_special(double x, double y)
+{
+    if (x != x) return x;                                                          // NaN
+    const double big = __builtin_huge_val();
+    if (x == 0.0) return y < 0.0 ? big : 0.0;                                      // +-0 (not an odd integer y)
+    if (x == big || x == -big) return y < 0.0 ? 0.0 : big;                         // +-inf (not an odd integer y)
+    return __builtin_nan("");                                                      // negative finite x, non-integer y
+}
 __device__ __forceinline__ double spc_pow(double x, double y)
 {
-    if (!(x > 0.0 && x <= 1.7976931348623157e308)) {
-        if (x != x) return x;                                                      // NaN
-        const double big = __builtin_huge_val();
-        if (x == 0.0) return y < 0.0 ? big : 0.0;                                  // +-0 (not an odd integer y)
-        if (x == big || x == -big) return y < 0.0 ? 0.0 : big;                     // +-inf (not an odd integer y)
-        return __builtin_nan("");                                                  // negative finite x, non-integer y
-    }
+    if (!(x > 0.0 && x <= 1.7976931348623157e308)) return spc_pow_special(x, y);
     return spc_pow_pos(x, y);
 }
-// the same with the polynomial coefficients in scalar registers (spc_pow.h: spc_pow_pos_tab): the standalone exner operator
-__device__ __forceinline__ double spc_pow_scalar_coef(double x, double y)
+// (p / pref0) ** y of the standalone exner operator (sputils.py:29,34), which is bound by VALU issue: the polynomial
+// coefficients come from scalar registers (spc_pow.h: spc_pow_pos_tab), and pressures in [2^-900, 2^900] -- all there are -- take
+// the quotient from Markstein's iteration (spc_pow.h: correctly rounded, 5 operations) and are known to be positive and
+// finite afterwards; anything else divides and may end in the special values.  Same bits as spc_pow(p / pref0, y).
+__device__ __forceinline__ double spc_exner_pow(double p, double y)
 {
-    if (!(x > 0.0 && x <= 1.7976931348623157e308)) return spc_pow(x, y);      // the special values, as above
+    double x;
+    if (__builtin_expect(p >= 0x1p-900 && p <= 0x1p+900, 1)) {
+        x = spc_div_pref0_markstein(p);
+    } else {
+        x = p / 1e5;
+        if (!(x > 0.0 && x <= 1.7976931348623157e308)) return spc_pow_special(x, y);
+    }
     return spc_pow_pos_tab(x, y);
 }
 #endif
@@ -113,9 +125,9 @@ __device__ __forceinline__ float spc_pow(float x, float y) { return powf(x, y); 
 #endif
 
 #if SPC_FASTPOW || SPC_EXP >= 2 || defined(SPC_OCML_POW)      // diagnostic builds: one pow for everything
-__device__ __forceinline__ double spc_pow_scalar_coef(double x, double y) { return spc_pow(x, y); }
+__device__ __forceinline__ double spc_exner_pow(double p, double y) { return spc_pow(SPC_DIV(p, 1e5), y); }
 #endif
-__device__ __forceinline__ float spc_pow_scalar_coef(float x, float y) { return spc_pow(x, y); }
+__device__ __forceinline__ float spc_exner_pow(float p, float y) { return spc_pow(SPC_DIV(p, 1e5f), y); }
 
 // Streaming accesses of the hot kernels: every input element is read once and every output written
 // once per launch.  -DSPC_NT=1 marks them non-temporal (experiment switch).

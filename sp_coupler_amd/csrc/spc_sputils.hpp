@@ -24,7 +24,7 @@
 //   * rms: 8 lanes per row = the 8 accumulators of numpy's leaf, combined by shuffles in numpy's order (64-B segments,
 //     no LDS, 8 x the parallelism per row);
 //   * exner: 4 elements per thread, loads up front, 4 independent pow chains, one pass over an uncapped grid; the pow's 21
-//     polynomial coefficients come from a __constant__ table, i.e. scalar registers (spc_pow_scalar_coef: a 64-bit literal costs
+//     polynomial coefficients come from a __constant__ table, i.e. scalar registers (spc_exner_pow: a 64-bit literal costs
 //     two v_mov per use, 26 % of the instructions of a pow; the operator is bound by VALU issue);
 //   * the searches run on NaN-padded LDS rows with a fixed trip count (su_count, spc_hip.hip), addresses are a uniform base + a
 //     32-bit byte offset (su_at).
@@ -141,22 +141,29 @@ template <int SL, typename T> __device__ __forceinline__ T su_interp_pad(const T
 }
 
 // ---- exner ---------------------------------------------------------------------------------------------------------
+#ifndef SU_EX_PER        // elements per thread: 2 -> 11.1-11.3 us at 35 718 x 91 elements, 4 -> 11.4-11.5, 6 -> 12.2 (profiles/r04_k7_slab_sweep.log)
+#define SU_EX_PER 2
+#endif
 template <typename T, int WT> __global__ __launch_bounds__(SU_THREADS) void k_exner(int64_t n, const T *p, T *out, int inverse)
 {
+    constexpr int PER = SU_EX_PER;
     const T y = inverse ? (-K<T>::rd) / K<T>::cp : K<T>::rd / K<T>::cp;                  // sputils.py:34 / 29
-    const int64_t i0 = (int64_t)blockIdx.x * (SU_THREADS * 4) + threadIdx.x;
-    T v[4];
+    const int64_t b0 = (int64_t)blockIdx.x * (SU_THREADS * PER);                         // the workgroup's first element: uniform
+    const int left = (int)((n - b0) < SU_THREADS * PER ? (n - b0) : SU_THREADS * PER);
+    const T *const pb = p + b0;                                                          // uniform bases + 32-bit offsets
+    T *const ob = out + b0;
+    T v[PER];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int64_t i = i0 + u * SU_THREADS;
-        v[u] = i < n ? ldg(p + i) : T(1);
+    for (int u = 0; u < PER; ++u) {
+        const int i = threadIdx.x + u * SU_THREADS;
+        v[u] = i < left ? ldg(su_at(pb, i)) : T(1);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = spc_pow_scalar_coef(div_pref0(v[u]), y);      // coefficients as scalar operands
+    for (int u = 0; u < PER; ++u) v[u] = spc_exner_pow(v[u], y);      // Markstein quotient, coefficients as scalar operands
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int64_t i = i0 + u * SU_THREADS;
-        if (i < n) stg<WT>(out + i, v[u]);
+    for (int u = 0; u < PER; ++u) {
+        const int i = threadIdx.x + u * SU_THREADS;
+        if (i < left) stg<WT>(su_at(ob, i), v[u]);
     }
 }
 

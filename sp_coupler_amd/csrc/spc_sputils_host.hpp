@@ -19,7 +19,7 @@ template <typename T> int exner_impl(int64_t n, const void *p, void *out, int in
     if (n < 0) return fail(SPC_ERR_INVALID_ARGUMENT, "%sexner: n < 0");
     if (n == 0) return SPC_OK;
     REQUIRE(p, "p"); REQUIRE(out, "out");
-    const int64_t per = (int64_t)SU_THREADS * 4;
+    const int64_t per = (int64_t)SU_THREADS * SU_EX_PER;
     if ((n + per - 1) / per > 0x7fffffff) return fail(SPC_ERR_UNSUPPORTED, "%sexner: more than 2^41 elements");
     auto kern = SU_PICK_WT((k_exner<T, 1>), (k_exner<T, 0>), n * (int64_t)sizeof(T));
     hipLaunchKernelGGL(kern, dim3((unsigned)((n + per - 1) / per)), dim3(SU_THREADS), 0, (hipStream_t)stream, n, (const T *)p, (T *)out, inverse);

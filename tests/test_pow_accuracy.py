@@ -19,3 +19,14 @@ def test_spc_pow_is_within_0_6_ulp_of_the_exact_power(tmp_path):
         worst = float(re.search(r"worst ([0-9.]+) ulp", ln).group(1))
         above = float(re.search(r"> 0.6 ulp ([0-9.e+-]+)", ln).group(1))
         assert worst <= 0.6 and above == 0.0, ln
+
+
+def test_markstein_quotient_is_the_division(tmp_path):
+    """the standalone exner operator forms p / pref0 by Markstein's iteration (spc_pow.h: spc_div_pref0_markstein) -- the same
+    source on the host against the division: random mantissas over [2^-900, 2^900], atmospheric pressures, arguments next to
+    exact multiples of 1e5 (quotients next to representable numbers), the window's edges"""
+    exe = str(tmp_path / "pow_accuracy")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-mfma", "-o", exe, os.path.join(ROOT, "tools", "csrc", "pow_accuracy.c"), "-lm"],
+                   check=True)
+    r = subprocess.run([exe, "20000000", "d"], capture_output=True, text=True)
+    assert r.returncode == 0 and re.search(r"80000004 arguments, 0 differ", r.stdout), r.stdout + r.stderr

@@ -82,6 +82,22 @@ def test_exner_accuracy_and_shapes(sputils):
     assert isinstance(r, torch.Tensor) and r.is_cuda and numpy.array_equal(r.cpu().numpy(), sputils.iexner(p))
 
 
+def test_exner_quotient_window_and_special_values(sputils):
+    """the operator forms p / pref0 by Markstein's iteration for p in [2^-900, 2^900] and by a division outside; both sides of
+    both edges, subnormal, huge, zero, negative, infinite and NaN pressures against numpy's (p / pref0) ** k"""
+    p = numpy.array([2.0 ** -900, numpy.nextafter(2.0 ** -900, 0), 2.0 ** -901, 2.0 ** 900, numpy.nextafter(2.0 ** 900, numpy.inf),
+                     2.0 ** 901, 5e-324, 2.3e-308, 1.7e308, 0.0, -0.0, -1.0, -1e5, numpy.inf, -numpy.inf, numpy.nan, 1e5, 101325.0, 1.0])
+    for fn, k in ((sputils.exner, sputils.rd / sputils.cp), (sputils.iexner, -sputils.rd / sputils.cp)):
+        with numpy.errstate(all="ignore"):
+            want = (p / sputils.pref0) ** k
+        got = fn(p)
+        assert numpy.array_equal(numpy.isnan(got), numpy.isnan(want)), (got, want)
+        fin = numpy.isfinite(want)
+        assert numpy.array_equal(got[~fin & ~numpy.isnan(want)], want[~fin & ~numpy.isnan(want)])          # +-inf where numpy has them
+        assert (numpy.abs(got[fin] - want[fin]) <= 2 * EPS * numpy.abs(want[fin])).all(), (got, want)
+    # (the quotient bit for bit: K1's thl, which divides, against this operator on 3e7 pressures in tests/test_cross_kernel_gpu.py)
+
+
 def _interp_rows(x, xp, fp):
     n = max(a.shape[0] if a.ndim == 2 else 1 for a in (x, xp, fp))
     row = lambda a, r: a[r] if a.ndim == 2 else a      # noqa: E731

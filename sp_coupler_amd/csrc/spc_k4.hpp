@@ -42,6 +42,21 @@ template <int D, typename F> __device__ __forceinline__ auto vn_pw(const F &term
     }
 }
 
+// numpy's plain loop for 1 <= n < 8 terms (pairwise_sum's first branch: res = 0; res += a[i]) with ALL the terms fetched before
+// the first addition: the loop as written waits for an LDS round trip per term (a dependent chain of n reads), this one for one.
+// Terms beyond n re-read term 0 (readable: n >= 1) and are not added.
+template <typename F> __device__ __forceinline__ auto vn_short(const F &term, int n) -> decltype(term(0))
+{
+    using T = decltype(term(0));
+    T t[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) t[i] = term(i < n ? i : 0);
+    T res = T(0);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) res = i < n ? res + t[i] : res;
+    return res;
+}
+
 // NG / NL != 0: level counts fixed at compile time and contiguous columns (as k_forward / k_backward): the flat-index
 // divisions become multiply-shifts.
 // PD (run-time geometry only): numpy's recursion unrolled to PD levels, enough for every layer of <= nL cells when
@@ -230,8 +245,18 @@ constexpr int k4_sl(int nL) { return cfloor_pow2(nL - 1) == 64 ? 7 : cfloor_pow2
 
 // (the unroll request of the register-stash loop is not honoured for the 137 <-> 512 instantiations -- their loop body, two
 //  levels of numpy's recursion, is too large -- where the stash is then addressed through the loop counter: no scratch either)
+// (column, entry) of item e of a [CB x n] slab with CB <= 2: a compare instead of the magic-number division (v_mul_hi_u32: quarter rate)
+template <int CB> __device__ __forceinline__ void k4_split(int e, int n, int &c, int &j)
+{
+    if constexpr (CB == 1) { c = 0; j = e; }
+    else { c = e >= n ? 1 : 0; j = e - (c ? n : 0); }
+}
+
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wpass-failed"
+#ifndef K4_SKIP          // diagnostic builds only (-DK4_SKIP=1): no cell scans, no layer sums -- what the kernel's memory side alone costs
+#define K4_SKIP 0
+#endif
 #ifndef SPC_K4_WAVES     // waves per SIMD the register allocator is asked to fit (6 = 80 VGPRs: six workgroups per CU)
 #define SPC_K4_WAVES 6
 #endif
@@ -257,7 +282,8 @@ template <typename T, int NG, int NL, int CB> __global__ __launch_bounds__(BLOCK
 
     // ---- stage: products per cell, the grid, the GCM half levels; start_index from Zf on the way -------------------------
     for (int e = tid; e < ncol * nL; e += tid_n) {
-        const int c = e / nL, l = e - c * nL;
+        int c, l;
+        k4_split<CB>(e, nL, c, l);
         const int64_t o = (col0 + c) * pitchL + l;
         const T t = p.t_d[o], qt = p.qt_d[o], ql = p.ql_d[o], qi = p.ql_ice_d[o], u = p.u_d[o], v = p.v_d[o], w = p.rhobf_d[o];
         T *const s = lds + (size_t)c * per_col + l;
@@ -274,14 +300,16 @@ template <typename T, int NG, int NL, int CB> __global__ __launch_bounds__(BLOCK
         const T nan = T(0) / T(0);
         const int nz = d.shared_grid ? ZROW : ncol * ZROW;
         for (int e = tid; e < nz; e += tid_n) {
-            const int c = e / ZROW, j = e - c * ZROW;
+            int c, j;
+            k4_split<CB>(e, ZROW, c, j);
             lzh[e] = j < nL ? (d.shared_grid ? p.zh[j] : p.zh[(col0 + c) * pitchL + j]) : nan;
         }
         if (d.shared_grid)
             for (int e = tid; e < nL - 1; e += tid_n) ldz[e] = p.zh[e + 1] - p.zh[e];    // sputils.py:146 / 154 / 159: z[i+1] - z[i]
     }
     for (int e = tid; e < ncol * (nG + 1); e += tid_n) {
-        const int c = e / (nG + 1), k = e - c * (nG + 1);
+        int c, k;
+        k4_split<CB>(e, nG + 1, c, k);
         const int64_t col = col0 + c, gh = col * pitchGh;
         T *const s = lds + (size_t)c * per_col;
         const T zs = p.Zghalf ? p.Zghalf[gh + nG] : T(0);
@@ -307,12 +335,13 @@ template <typename T, int NG, int NL, int CB> __global__ __launch_bounds__(BLOCK
     //      ia = -1: layer above the LES top (Q stays 0, sputils.py:187); -2: an end point outside zh (None -> NaN);
     //      ib < 0 encodes sign = -1 (sputils.py:117-120).
     for (int e = tid; e < n1; e += tid_n) {
-        const int c = e / nG, k = e - c * nG;
+        int c, k;
+        k4_split<CB>(e, nG, c, k);
         T *const s = lds + (size_t)c * per_col;
         const T *const z = d.shared_grid ? lzh : lzh + (size_t)c * ZROW;
         const T *const Zh = s + o_Zh;
         int ia = -1, ib = -1;
-        if (Zh[k] < z[nL - 1]) {                                                         // sputils.py:187
+        if (K4_SKIP == 0 && Zh[k] < z[nL - 1]) {                                                         // sputils.py:187
             T a = Zh[k + 1], b = Zh[k];
             if (a < z[0] || a > z[nL - 1] || b < z[0] || b > z[nL - 1]) {
                 ia = -2;                                                                 // sputils.py:113-115
@@ -338,7 +367,9 @@ template <typename T, int NG, int NL, int CB> __global__ __launch_bounds__(BLOCK
         const int e = tid + it * BLOCK;
         T X = T(0);                                                                      // Q = zeros (sputils.py:185)
         if (e < n1 * 8) {
-            const int f = e & 7, ck = e >> 3, c = ck / nG, k = ck - c * nG;
+            const int f = e & 7, ck = e >> 3;
+            int c, k;
+            k4_split<CB>(ck, nG, c, k);
             const T *const s = lds + (size_t)c * per_col;
             const T *const z = d.shared_grid ? lzh : lzh + (size_t)c * ZROW;
             const int pk = reinterpret_cast<const int *>(s + o_cell)[k], ia = (int)(short)(pk & 0xffff);
@@ -354,10 +385,12 @@ template <typename T, int NG, int NL, int CB> __global__ __launch_bounds__(BLOCK
                 T S;
                 if (d.shared_grid) {
                     const T *const dz = ldz + ia;
-                    S = T(0) + vn_pw<vn_pw_depth(NL)>([&](int i) { return a[i] * dz[i]; }, 0, cnt);       // sputils.py:152 / 157
+                    const auto term = [&](int i) { return a[i] * dz[i]; };                   // sputils.py:152 / 157
+                    S = cnt < 8 ? T(0) + vn_short(term, cnt) : T(0) + vn_pw<vn_pw_depth(NL)>(term, 0, cnt);
                 } else {
                     const T *const zz = z + ia;
-                    S = T(0) + vn_pw<vn_pw_depth(NL)>([&](int i) { return a[i] * (zz[i + 1] - zz[i]); }, 0, cnt);
+                    const auto term = [&](int i) { return a[i] * (zz[i + 1] - zz[i]); };
+                    S = cnt < 8 ? T(0) + vn_short(term, cnt) : T(0) + vn_pw<vn_pw_depth(NL)>(term, 0, cnt);
                 }
                 const T za = s[o_Zh + k + 1], zb = s[o_Zh + k];                          // a, b of integral() before the swap
                 const T da = (swap ? zb : za) - z[ia], db = z[ib + 1] - (swap ? za : zb);   // sputils.py:154,159
@@ -373,7 +406,9 @@ template <typename T, int NG, int NL, int CB> __global__ __launch_bounds__(BLOCK
     for (int it = 0; it < MAXIT; ++it) {
         const int e = tid + it * BLOCK;
         if (e < n1 * 8) {
-            const int f = e & 7, ck = e >> 3, c = ck / nG, k = ck - c * nG;
+            const int f = e & 7, ck = e >> 3;
+            int c, k;
+            k4_split<CB>(ck, nG, c, k);
             if (f < 7) lds[(size_t)c * per_col + (size_t)f * nG + k] = Xr[it];           // X[7][nG] over the product arrays
         }
     }
@@ -382,7 +417,8 @@ template <typename T, int NG, int NL, int CB> __global__ __launch_bounds__(BLOCK
 
     // ---- tendencies: flat over the [ncol x nG] slab, as K3 (spcpl.py:498, 518-533) --------------------------------------
     for (int e = tid; e < n1; e += tid_n) {
-        const int c = e / nG, k = e - c * nG;
+        int c, k;
+        k4_split<CB>(e, nG, c, k);
         const int64_t col = col0 + c, cg = col * pitchG, g = cg + k;
         const T *const s = lds + (size_t)c * per_col;
         const GcmIn<T> in = load_gcm(p, g, cg + (nG - 1 - k));

@@ -56,7 +56,7 @@ struct SuWalk {
     __device__ __forceinline__ SuWalk(int tid, int n_) : n(n_)
     {
         // tid / n for tid < 256 without a vector division: (tid * ceil(2^16 / n)) >> 16 is exact while 255 n < 2^16
-        const int m = (65536 + n - 1) / n;                       // uniform
+        const int m = n < SU_THREADS ? (65536 + n - 1) / n : 0;  // uniform
         r = n < SU_THREADS ? (int)(__umul24((unsigned)tid, (unsigned)m) >> 16) : (tid >= n ? 1 : 0);
         i = tid - su_mul(r, n);
         dr = SU_THREADS / n; di = SU_THREADS - dr * n;

@@ -200,7 +200,8 @@ int spc_variability_nudge_f64(const spc_vnudge_args *args, void *stream);
  * own (sp_coupler_amd/sputils.py keeps the reference's names on top of them).  A "row" is one independent 1-D problem
  * (one column); arrays are [n_rows x n] with an element pitch between rows; where stated a pitch of 0 means ONE row
  * shared by all rows (the LES grid).  Results are bit-identical to NumPy for interp / searchsorted / integral /
- * interp_c / interp_rho / rms; exner / iexner agree with numpy.power to <= 2 ulp.                                  */
+ * interp_c / interp_rho / rms; exner / iexner agree with numpy.power to <= 2 ulp.  Row pitches must stay below 2^24
+ * elements (SPC_ERR_UNSUPPORTED otherwise): the kernels address a slab of rows with 24-bit multiplies.                */
 
 /* sputils.exner (inverse == 0) / iexner (inverse != 0), splib/sputils.py:28-34: out[i] = (p[i]/pref0)**(+-rd/cp)   */
 int spc_exner_f64(int64_t n, const void *p, void *out, int32_t inverse, void *stream);

@@ -143,6 +143,23 @@ def test_interp_errors_like_numpy(sputils):
         sputils.interp(numpy.zeros(3), numpy.arange(4.), numpy.arange(4.), period=360.0)
 
 
+def test_row_pitches_of_2_pow_24_elements_are_refused():
+    """the staged kernels form row offsets with 24-bit multiplies: a pitch of 2^24 elements or more is SPC_ERR_UNSUPPORTED, one
+    element less is served (and right)"""
+    from sp_coupler_amd import _abi, spcpl
+    eng = spcpl.get_engine()
+    wide = torch.zeros((2, 2 ** 24), dtype=torch.float64, device="cuda")
+    xp = torch.tensor([0.0, 1.0, 2.0], dtype=torch.float64, device="cuda")
+    wide[:, :3] = torch.tensor([[10.0, 20.0, 30.0], [1.0, 2.0, 3.0]], dtype=torch.float64, device="cuda")
+    x = torch.tensor([0.5, 1.5], dtype=torch.float64, device="cuda")
+    with pytest.raises(_abi.SpcError) as e:
+        eng.interp(x, xp, wide[:, :3])
+    assert e.value.code == _abi.SPC_ERR_UNSUPPORTED and "2^24" in str(e.value)
+    near = wide.view(-1)[:2 * (2 ** 24 - 1)].view(2, 2 ** 24 - 1)            # rows 2^24 - 1 elements apart
+    near[:, :3] = torch.tensor([[10.0, 20.0, 30.0], [1.0, 2.0, 3.0]], dtype=torch.float64, device="cuda")
+    assert numpy.array_equal(eng.interp(x, xp, near[:, :3]).cpu().numpy(), [[15.0, 25.0], [1.5, 2.5]])
+
+
 def test_searchsorted_is_numpy_searchsorted(sputils):
     rng = numpy.random.default_rng(6)
     n, n_a, n_v = 200, 160, 92

@@ -218,31 +218,89 @@ def sample_rows(n, m=4096):
     return numpy.unique(numpy.concatenate([numpy.arange(a), mid, numpy.arange(n - a, n)]))
 
 
+# fp32 arithmetic variant (BASELINE config 5's tolerance sweep): outputs against the fp64 oracle ON THE SAME (rounded) INPUTS.
+# A forcing / tendency is factor (x_interpolated - x_model) / dt, a difference of nearly equal numbers, so its fp32 error is
+# set by the PROFILE's scale: the statistic is max |err| dt / (|factor| max |profile|).  Bars = 5-10x what
+# tests/test_fullsize_gpu.py::test_fp32_vs_fp64_tolerance_sweep_config5 measures.
+F32_TOL = {"f_u": 1e-4, "f_v": 1e-4, "f_thl": 1e-5, "f_qt": 1e-4, "f_ql": 5e-4, "ql_ref": 5e-4, "f_ps": 1e-5,
+           "f_T": 1e-5, "f_SH": 1e-4, "f_QL": 5e-4, "f_QI": 5e-4, "f_U": 1e-4, "f_V": 1e-4, "f_A": 1e-5}
+F32_IDX_MISMATCH_MAX = 0.01       # half levels within fp32 rounding of an LES half level land one cell off
+F32_MASK_MISMATCH_MAX = 1e-3      # GCM levels within fp32 rounding of the LES top: masked in one arithmetic, not the other
+
+
+def compare_with_oracle_f32(F, B, ref_f, ref_b, scales, factor, dt):
+    """fp32 outputs against fp64 oracle outputs of the same rows; ``scales``: max |profile| per output name.
+    Returns (failures, detail)."""
+    import numpy
+    bad, det = [], {}
+    for name, got, want in [(k, F[k], ref_f[k]) for k in ("f_u", "f_v", "f_thl", "f_qt", "f_ql", "ql_ref", "f_ps")] + \
+                           [(k, B[k], ref_b[k]) for k in ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A")]:
+        got = got.astype(numpy.float64)
+        live = ~(numpy.isnan(want) | numpy.isnan(got))
+        # masked above the LES top in one arithmetic only (f[0:start_index] *= 0, spcpl.py:527-533): counted, not measured
+        off = live & ((want == 0) != (got == 0)) if name in B else numpy.zeros_like(live)
+        nanoff = numpy.isnan(want) != numpy.isnan(got)
+        mm = float((off | nanoff).mean())
+        use = live & ~off
+        unit = 1.0 if name == "ql_ref" else abs(factor) / dt
+        err = float(numpy.abs(got[use] - want[use]).max() / (scales[name] * unit)) if use.any() else 0.0
+        det[name] = {"max_err_over_profile_scale": err, "mask_mismatch_fraction": mm}
+        if not err <= F32_TOL[name]:
+            bad.append("%s: fp32 error %.3e of the profile scale > %.1e" % (name, err, F32_TOL[name]))
+        if mm > F32_MASK_MISMATCH_MAX:
+            bad.append("%s: %.2e of the elements masked / NaN in one arithmetic only" % (name, mm))
+    if "idx" in F:
+        mis = float((F["idx"] != ref_f["idx"].astype(F["idx"].dtype)).mean())
+        det["idx_mismatch_fraction"] = mis
+        if mis > F32_IDX_MISMATCH_MAX:
+            bad.append("idx: %.3e of the level indices differ" % mis)
+    return bad, det
+
+
+def f32_scales(gs, ps, ref_f):
+    import numpy
+    mx = lambda a: float(numpy.abs(a[numpy.isfinite(a)]).max())                       # noqa: E731
+    return {"f_u": mx(ref_f["u"]), "f_v": mx(ref_f["v"]), "f_thl": mx(ref_f["thl"]), "f_qt": mx(ref_f["qt"]),
+            "f_ql": max(mx(ref_f["ql_ref"]), 1e-4), "ql_ref": max(mx(ref_f["ql_ref"]), 1e-4), "f_ps": mx(ps["PS"]),
+            "f_T": mx(ps["T"]), "f_SH": mx(ps["QT"]), "f_QL": max(mx(ps["QL"]), 1e-4), "f_QI": max(mx(ps["QL"]), 1e-4),
+            "f_U": mx(ps["U"]), "f_V": mx(ps["V"]), "f_A": 1.0}
+
+
 def sample_check(fout, bout, g, p, zf, zh, factor, dt, m=4096):
     """A sample of the rows of one device's block (``sample_rows``): the inputs the kernels read are fetched FROM THE
     DEVICE, run through the plain-C oracle (tests/oracle_c.py: oracle/spc_oracle.c, the independent restatement with the
     ABI's own argument structs) on the host, and compared with the outputs the timed plans left in HBM.  ``fout`` /
     ``bout``: output dicts of the forward / backward plan; ``g`` / ``p``: the device tensors the plans were built on.
-    Used where no CPU copy of the batch exists: the ranks of an N > 1 run, the devices of in_process_all_gpus."""
+    Used where no CPU copy of the batch exists: the ranks of an N > 1 run, the devices of in_process_all_gpus, the
+    `config5` / `per_column_grid` legs.  float64 tensors: bit comparison (f_thl within 8 ulp of thl / dt); float32
+    tensors: the fp64 oracle on the SAME rounded inputs, tolerances F32_TOL.  zf / zh: [nL] or one row per column."""
     import numpy
     import torch
     from tests import oracle_c
     n = int(g["T"].shape[0])
+    f32 = g["T"].dtype == torch.float32
     rows = sample_rows(n, m)
     rt = torch.from_numpy(rows).to(g["T"].device)
     take = lambda t: numpy.ascontiguousarray(t.index_select(0, rt).cpu().numpy())       # noqa: E731
-    gs = {k: take(v) for k, v in g.items() if k in ("U", "V", "T", "SH", "QL", "QI", "Pfull", "Phalf", "A", "Zgfull", "Zghalf")}
-    ps = {k: take(v) for k, v in p.items() if k in ("U", "V", "THL", "QT", "QL", "QL_ice", "T", "PS", "A")}
+    take64 = lambda t: numpy.ascontiguousarray(take(t), dtype=numpy.float64)             # noqa: E731
+    gs = {k: take64(v) for k, v in g.items() if k in ("U", "V", "T", "SH", "QL", "QI", "Pfull", "Phalf", "A", "Zgfull", "Zghalf")}
+    ps = {k: take64(v) for k, v in p.items() if k in ("U", "V", "THL", "QT", "QL", "QL_ice", "T", "PS", "A")}
     ps["Rain"], ps["rain_last"] = numpy.zeros(len(rows)), numpy.zeros(len(rows))
-    zfn, zhn = numpy.ascontiguousarray(zf.cpu().numpy()), numpy.ascontiguousarray(zh.cpu().numpy())
+    grid = lambda z: take64(z) if z.dim() == 2 else numpy.ascontiguousarray(z.cpu().numpy(), dtype=numpy.float64)   # noqa: E731
+    zfn, zhn = grid(zf), grid(zh)
     ref_f = oracle_c.forward(gs, zfn, zhn, ps, factor, dt, couple_surface=False)
     ref_b = oracle_c.backward(gs, None, zfn, ps, factor, dt)
     F = {k: take(v) for k, v in fout.items()}
     B = {k: take(v) for k, v in bout.items()}
-    bad, det = compare_with_oracle(F, B, ref_f, ref_b, factor, dt)
-    return (not bad), {"rows_checked": int(len(rows)), "first_row": int(rows[0]), "last_row": int(rows[-1]), "rows_in_block": n,
-                       "oracle": "oracle/spc_oracle.c (plain C, glibc pow) on inputs read back from the device",
-                       "f_thl_max_rel_err": det["f_thl_max_rel_err"], "failures": bad}
+    res = {"rows_checked": int(len(rows)), "first_row": int(rows[0]), "last_row": int(rows[-1]), "rows_in_block": n,
+           "oracle": "oracle/spc_oracle.c (plain C, glibc pow, fp64) on inputs read back from the device"}
+    if f32:
+        bad, det = compare_with_oracle_f32(F, B, ref_f, ref_b, f32_scales(gs, ps, ref_f), factor, dt)
+        res.update({"fp32_vs_fp64_oracle": det, "tolerances": F32_TOL, "failures": bad})
+    else:
+        bad, det = compare_with_oracle(F, B, ref_f, ref_b, factor, dt)
+        res.update({"f_thl_max_rel_err": det["f_thl_max_rel_err"], "failures": bad})
+    return (not bad), res
 
 
 def device_identity(index):
@@ -544,9 +602,11 @@ def in_process_all_gpus(ids, factor, dt, args):
 class Workload:
     """ROTATE batches of one configuration resident in HBM + the exchange plans bench.py times."""
 
-    def __init__(self, eng, n_cols, nG, nL, seed, rotate, factor, dt, cols_per_block=0, keep_host=False):
+    def __init__(self, eng, n_cols, nG, nL, seed, rotate, factor, dt, cols_per_block=0, keep_host=False, per_column_grid=False):
         from sp_coupler_amd import synthetic
         self.n_cols, self.nG, self.nL, self.rotate = n_cols, nG, nL, rotate
+        self.esize = 8 if eng.dtype.itemsize == 8 else 4
+        self.bytes = algorithmic_bytes(nG, nL, self.esize, shared_grid=not per_column_grid)
         self.fplans, self.bplans, self.host0 = [], [], None
         need = ("U", "V", "T", "SH", "QL", "QI", "Pfull", "Phalf", "A", "Zgfull", "Zghalf",      # what the two plans read
                 "THL", "QT", "QL_ice", "PS")
@@ -554,7 +614,8 @@ class Workload:
             # columns beyond the first 8192 are tiles of those with a per-tile perturbation, made ON THE DEVICE (same bits
             # as synthetic.make_batch_tiled on the host; tile 0 is the host batch `verified` checks)
             g, zf_d, zh_d, p, host = synthetic.make_batch_tiled_device(eng.device, n_cols, nG, nL, seed=seed + r,
-                                                                        couple_surface=False, keys=need)
+                                                                        couple_surface=False, keys=need, dtype=eng.dtype,
+                                                                        per_column_grid=per_column_grid)
             if r == 0:
                 self.inputs0 = (g, zf_d, zh_d, p)      # device tensors of batch 0 (sample_check reads its rows back)
             if r == 0 and keep_host:
@@ -598,6 +659,51 @@ class Workload:
             torch.cuda.synchronize()
             res[name] = e0.elapsed_time(e1) * 1e3 / launches
         return res["k1"], res["k3"]
+
+
+def config_leg(device, cfg, dtype_name, per_column_grid, factor, dt, steps=100, launches=100, check_rows=4096, cols_per_block=0):
+    """One extra workload of the N = 1 line on the SHIPPED library (round-4 verdict, items 1 and 3): BASELINE config ``cfg``
+    in the arithmetic type ``dtype_name`` ('f64' / 'f32'), LES grid shared or one row per column (north_star's literal
+    layout); whole steps, per-kernel HIP events, algorithmic bytes at the element size, and ``sample_check`` of what the
+    timed plans left in HBM (bit comparison for fp64, F32_TOL for fp32)."""
+    import torch
+    from sp_coupler_amd import synthetic
+    from sp_coupler_amd.engine import Engine
+    eng = Engine(device, dtype=torch.float64 if dtype_name == "f64" else torch.float32)
+    stream = torch.cuda.current_stream(eng.device)
+    sptr = ctypes.c_void_p(stream.cuda_stream)
+    n, nG, nL, seed = synthetic.CONFIGS[cfg]
+    esize = 8 if dtype_name == "f64" else 4
+    ab = algorithmic_bytes(nG, nL, esize, shared_grid=not per_column_grid)
+    rotate = 1 if n * ab["exchange"] > 2e9 else 2           # one batch of > 2 GB is already > 8x the Infinity Cache
+    wl = Workload(eng, n, nG, nL, seed, rotate, factor, dt, cols_per_block, per_column_grid=per_column_grid)
+    wl.heat(sptr)
+    for i in range(3):
+        wl.step(i, sptr)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        wl.step(i, sptr)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    k1, k3 = wl.kernel_times(stream, sptr, launches=launches)
+    try:
+        ok, det = sample_check(wl.fplans[0].outputs, wl.bplans[0].outputs, *wl.inputs0, factor, dt, m=check_rows)
+    except Exception as e:
+        ok, det = False, {"failures": ["sample_check raised %r" % (e,)]}
+    res = {"workload": "config %d: %d synthetic SP columns on one GPU, %d GCM <-> %d LES levels, %s, %s, %d batch(es) resident in HBM"
+                       % (cfg, n, nG, nL, "fp64" if esize == 8 else "fp32", "LES grid PER COLUMN [n_cols x n_lev]" if per_column_grid else "shared LES grid", rotate),
+           "dtype": dtype_name, "value": n * steps / el, "unit": "column-exchanges/s", "steps": steps, "ms_per_step": el / steps * 1e3,
+           "bytes_per_exchange": ab["exchange"], "hbm_frac_whole_step": n * steps / el * ab["exchange"] / 1e9 / HBM_PEAK_GBS,
+           "k1_avg_launch_us": k1, "k3_avg_launch_us": k3, "launches_timed": launches,
+           "k1_kernel": wl.fplans[0].describe(), "k3_kernel": wl.bplans[0].describe(),
+           "k1_algorithmic_bytes_per_launch": ab["k1_launch"] * n, "k3_algorithmic_bytes_per_launch": ab["k3_launch"] * n,
+           "k1_frac": ab["k1_launch"] * n / (k1 * 1e-6) / 1e9 / HBM_PEAK_GBS,
+           "k3_frac": ab["k3_launch"] * n / (k3 * 1e-6) / 1e9 / HBM_PEAK_GBS,
+           "verified": bool(ok), "check": det}
+    del wl
+    torch.cuda.empty_cache()
+    return res
 
 
 def self_launch(n_gpus, argv):
@@ -688,6 +794,11 @@ def main():
     ap.add_argument("--multi-devices", default=None,
                     help="N=1 extra `in_process_all_gpus`: config 4 through multi.MultiDeviceEngine on these device ids (default: every "
                          "visible GPU when there is more than one; '0,0' rehearses the path with two engines on one GPU; 'none' skips)")
+    ap.add_argument("--dtype", choices=("f64", "f32"), default="f64", help="arithmetic type of the headline workload (f64 as the reference; "
+                    "f32: the tolerance-sweep variant, checked against the fp64 oracle within F32_TOL)")
+    ap.add_argument("--per-column-grid", action="store_true", help="headline workload with the LES grid packed per column [n_cols x n_lev]")
+    ap.add_argument("--no-config5", action="store_true", help="skip the `config5` extra (88 838 columns 137<->512, f64 and f32) at N=1")
+    ap.add_argument("--no-per-column-grid-leg", action="store_true", help="skip the `per_column_grid` extra (config 3, grid per column) at N=1")
     ap.add_argument("--check-rows", type=int, default=4096, help="rows per rank / device in the N > 1 output check (sample_check)")
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="N>1 launch mechanics only (rendezvous, sharding, barrier, max-reduction over gloo; no GPU work): CPU tests")
@@ -744,12 +855,13 @@ def main():
     n_cols = hi - lo
     rotate = args.rotate or (8 if n_cols <= 4096 else 2)
     dt_gcm, factor = 900.0, 1.0
-    eng = Engine("cuda:%d" % local)
+    f32 = args.dtype == "f32"
+    eng = Engine("cuda:%d" % local, dtype=torch.float32 if f32 else torch.float64)
     stream = torch.cuda.current_stream(eng.device)
     sptr = ctypes.c_void_p(stream.cuda_stream)
 
     wl = Workload(eng, n_cols, nG, nL, seed + 1000 * rank, rotate, factor, dt_gcm, args.cols_per_block,
-                  keep_host=(rank == 0 and world == 1))
+                  keep_host=(rank == 0 and world == 1), per_column_grid=args.per_column_grid)
 
     def fence():
         torch.cuda.synchronize()
@@ -762,7 +874,7 @@ def main():
     # 10-13 % slower than steady state (profiles/r02_shortrun_clock_ramp.log, tools/shortrun.py), which is longer than
     # the driver's whole `--warmup 5 --steps 20` region.  `cold_clock` below reports the same W + K taken straight
     # after an idle gap.
-    ab = algorithmic_bytes(nG, nL)
+    ab = wl.bytes                            # at the element size, grid shared or per column
     k1_us = k3_us = None
     kdiag = {}
     copy_gbs = None
@@ -883,6 +995,26 @@ def main():
         del w4
         torch.cuda.empty_cache()
 
+    # BASELINE config 5 (137 <-> 512, the high-vertical-resolution case) in both arithmetic types, and config 3 with the LES
+    # grid packed per column: measured on the shipped library in EVERY default N = 1 line (round-4 verdict, items 1 and 3)
+    config5 = percol = None
+    plain = world == 1 and cfg == 3 and not args.cols and not f32 and not args.per_column_grid and not args.no_kernel_events
+    if plain and not args.no_config5:
+        config5 = {}
+        for dn in ("f64", "f32"):
+            try:
+                config5[dn] = config_leg(eng.device, 5, dn, False, factor, dt_gcm, steps=60, launches=60, check_rows=args.check_rows)
+            except Exception as e:                   # a reported extra, never fatal for the headline
+                config5[dn] = {"error": repr(e)}
+    if plain and not args.no_per_column_grid_leg:
+        try:
+            percol = config_leg(eng.device, 3, "f64", True, factor, dt_gcm, steps=200, launches=KERNEL_LAUNCHES, check_rows=args.check_rows)
+            if k1_us:
+                percol["k1_vs_shared_grid"] = percol["k1_avg_launch_us"] / k1_us
+                percol["k3_vs_shared_grid"] = percol["k3_avg_launch_us"] / k3_us
+        except Exception as e:
+            percol = {"error": repr(e)}
+
     inproc = None
     ids = None
     if world == 1 and args.multi_devices != "none" and not args.no_kernel_events:
@@ -926,18 +1058,20 @@ def main():
         return
 
     value = total_cols * args.steps / elapsed
+    gtxt = "LES grid PER COLUMN [n_cols x n_lev]" if args.per_column_grid else "shared LES grid"
+    ttxt = "fp32" if f32 else "fp64"
     if world == 1:
-        wtxt = ("config %d: %d synthetic SP columns on one GPU, %d GCM <-> %d LES levels, fp64, shared LES grid, "
-                "%d rotating batches resident in HBM" % (cfg, total_cols, nG, nL, rotate))
+        wtxt = ("config %d: %d synthetic SP columns on one GPU, %d GCM <-> %d LES levels, %s, %s, "
+                "%d rotating batches resident in HBM" % (cfg, total_cols, nG, nL, ttxt, gtxt, rotate))
     else:
         wtxt = ("config %d: %d synthetic SP columns column-sharded over %d GPUs (%d per GPU, contiguous row blocks), "
-                "%d GCM <-> %d LES levels, fp64, shared LES grid, %d rotating batches per GPU"
-                % (cfg, total_cols, world, n_cols, nG, nL, rotate))
+                "%d GCM <-> %d LES levels, %s, %s, %d rotating batches per GPU"
+                % (cfg, total_cols, world, n_cols, nG, nL, ttxt, gtxt, rotate))
     out = {
         "metric": "SP column-exchanges/sec (GCM<->LES forcing+tendency)",
         "value": value, "unit": "column-exchanges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": wtxt, "total_cols": total_cols, "n_cols_per_gpu": n_cols, "nG": nG, "nL": nL,
                    "rotate": rotate, "launches_per_step": 2, "parallelism": "columns sharded, no collective"},
         "backend": (args.backend if world > 1 else None),
@@ -967,7 +1101,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))     # PMC passes of tools/gpu_round.sh (separate --pmc runs, calibrated)
-                if tj.get("n_cols") == n_cols and (nG, nL) == (91, 160):
+                if tj.get("n_cols") == n_cols and (nG, nL) == (91, 160) and not f32 and not args.per_column_grid:
                     traffic = tj.get("k_forward_bytes_per_launch")
                     tsrc = "profiles/traffic.json (builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on another box, %s)" % tj.get("tag", "this round")
             except Exception:
@@ -995,6 +1129,10 @@ def main():
         out["small_batch"] = small
     if anchor is not None:
         out["scaling_anchor"] = anchor
+    if config5 is not None:
+        out["config5"] = config5
+    if percol is not None:
+        out["per_column_grid"] = percol
     if inproc is not None:
         out["in_process_all_gpus"] = inproc
     if dropin is not None:
@@ -1012,14 +1150,22 @@ def main():
         m = min(n_cols, 8192)             # bounded sample: the first m columns of batch 0, whole passes
         gs = {k: numpy.ascontiguousarray(v[:m]) for k, v in gcm.items()}
         ps = {k: numpy.ascontiguousarray(v[:m]) for k, v in prof.items()}
+        if args.per_column_grid:
+            zf, zh = numpy.ascontiguousarray(zf[:m]), numpy.ascontiguousarray(zh[:m])
         base, ref_f, ref_b = cpu_baseline(gs, zf, zh, ps, dt_gcm, factor, args.cpu_seconds)
         out["cpu_baseline"] = base
         # batch 0 was last written by the per-kernel loops above with the same inputs: check it
-        ok, detail = verify(wl.fplans[0], wl.bplans[0], ref_f, ref_b, m, factor, dt_gcm)
-        try:
-            detail["iexner_ulp_distance"] = pow_ulp_histogram(eng, gs["Pfull"][:2048])
-        except Exception as e:                           # a reported extra
-            detail["iexner_ulp_distance"] = {"error": repr(e)}
+        if f32:      # the fp32 variant: fp64 oracle on the unrounded inputs, tolerances F32_TOL (input rounding included)
+            F = {k: v.cpu().numpy()[:m] for k, v in wl.fplans[0].outputs.items()}
+            B = {k: v.cpu().numpy()[:m] for k, v in wl.bplans[0].outputs.items()}
+            bad, det = compare_with_oracle_f32(F, B, ref_f, ref_b, f32_scales(gs, ps, ref_f), factor, dt_gcm)
+            ok, detail = (not bad), {"columns_checked": int(m), "fp32_vs_fp64_oracle": det, "tolerances": F32_TOL, "failures": bad}
+        else:
+            ok, detail = verify(wl.fplans[0], wl.bplans[0], ref_f, ref_b, m, factor, dt_gcm)
+            try:
+                detail["iexner_ulp_distance"] = pow_ulp_histogram(eng, gs["Pfull"][:2048])
+            except Exception as e:                           # a reported extra
+                detail["iexner_ulp_distance"] = {"error": repr(e)}
         out["verified"], out["verified_detail"] = ok, detail
         workers = min(16, os.cpu_count() or 1)
         if workers > 1 and not args.no_cpu_multicore:
@@ -1034,6 +1180,10 @@ def main():
         dist.destroy_process_group()
     if out["verified"] is False:
         sys.exit("bench.py: outputs of the timed plans differ from the oracle: %s" % out["verified_detail"]["failures"])
+    legs = [("per_column_grid", percol)] + [("config5." + k, v) for k, v in (config5 or {}).items()]
+    wrong = [name for name, leg in legs if leg is not None and leg.get("verified") is False]
+    if wrong:
+        sys.exit("bench.py: outputs of the %s leg(s) differ from the oracle" % ", ".join(wrong))
     if dropin is not None and dropin.get("verified") is False:
         sys.exit("bench.py: the drop-in step delivered something else than the kernels compute: %s"
                  % [f for d in dropin["verified_detail"] for f in d["failures"]])

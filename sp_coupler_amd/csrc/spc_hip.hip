@@ -121,7 +121,27 @@ __device__ __forceinline__ double spc_exner_pow(double p, double y)
     return spc_pow_pos_tab(x, y);
 }
 #endif
-__device__ __forceinline__ float spc_pow(float x, float y) { return powf(x, y); }
+// the fp32 variant's power: spc_powf.h -- evaluated inside double arithmetic and rounded once (<= 0.5 + 2^-14 ulp, the host
+// sweep computes the device's bits), inline; rounds 1-4 called ocml's powf() out of line.  Special values as for double.
+#ifndef SPC_POW_FN
+#define SPC_POW_FN __device__ __forceinline__
+#endif
+#include "spc_powf.h"
+__device__ __forceinline__ float spc_pow(float x, float y)
+{
+#if defined(SPC_OCML_POW) || defined(SPC_OCML_POWF)     // A/B builds: ocml's powf (what rounds 1-4 shipped)
+    return powf(x, y);
+#else
+    if (!(x > 0.0f && x <= 3.4028234663852886e38f)) {
+        if (x != x) return x;                                                      // NaN
+        const float big = __builtin_huge_valf();
+        if (x == 0.0f) return y < 0.0f ? big : 0.0f;
+        if (x == big || x == -big) return y < 0.0f ? 0.0f : big;
+        return __builtin_nanf("");
+    }
+    return spc_powf_pos(x, y);
+#endif
+}
 #endif
 
 #if SPC_FASTPOW || SPC_EXP >= 2 || defined(SPC_OCML_POW)      // diagnostic builds: one pow for everything
@@ -957,6 +977,36 @@ void lds_elems(const spc_dims *d, int pass, bool with_idx, size_t *per_col, size
     }
 }
 
+int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+// Compute units of the CURRENT device (hipDeviceAttributeMultiprocessorCount; cached per device ordinal): what the residency
+// rules below count rounds of workgroups against.  An MI355X in SPX mode has 256; a CPX / DPX partition or another SKU
+// has fewer, and rule 1 of pick_cb would silently pick the wrong slab there (round-4 verdict, weak 10).  SPC_CUS=<n>
+// overrides (tests walk the heuristics at 32 ... 256 CUs without a GPU); without a device: 256.
+int device_cus()
+{
+    const int forced = env_int("SPC_CUS", 0);
+    if (forced > 0) return forced;
+    thread_local int cache[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 256;
+    }
+    if (dev >= 0 && dev < 64 && cache[dev]) return cache[dev];
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        n = 256;
+    }
+    if (dev >= 0 && dev < 64) cache[dev] = n;
+    return n;
+}
+
 // Resident workgroups per CU for `kernel` with `smem` bytes of dynamic LDS (occupancy API, cached).
 // Without a device (CPU-side ABI tests) falls back to min(4, 160 KiB / smem).
 template <typename KernelT> int blocks_per_cu(KernelT kernel, size_t smem)
@@ -978,7 +1028,7 @@ template <typename KernelT> int blocks_per_cu(KernelT kernel, size_t smem)
 }
 
 // Columns per workgroup (CB).
-//  1. If some CB in {1,2,4} lets the WHOLE grid be resident at once (n_cols/CB <= 256 CUs x resident
+//  1. If some CB in {1,2,4} lets the WHOLE grid be resident at once (n_cols/CB <= CUs of the device x resident
 //     workgroups per CU at that CB's LDS footprint), take the smallest such CB: a single round of
 //     workgroups, maximum parallelism per column (measured: 2048 columns run 13.3 us at CB=2 but 19-20 us
 //     at CB=1, which needs two rounds).
@@ -995,21 +1045,22 @@ template <typename KernelT> int pick_cb(const spc_dims *d, int pass, bool with_i
         return cb;
     }
     int nb[4] = {0, 0, 0, 0};
+    const int64_t cus = device_cus();
     for (int i = 0; i < 4; ++i) {
         cb = 1 << i;
         const size_t smem = (per_col * cb + fixed) * esize;
         if (cb > 1 && smem > (size_t)MAX_LDS_BYTES) continue;
         nb[i] = blocks_per_cu(kernel, smem);
-        if (cb <= 4 && (d->n_cols + cb - 1) / cb <= (int64_t)256 * nb[i]) return cb;   // rule 1
+        if (cb <= 4 && (d->n_cols + cb - 1) / cb <= cus * nb[i]) return cb;   // rule 1
     }
     // K4 is bound by dependent LDS reads, not by memory: what counts is resident COLUMNS (2 x 4 workgroups beat 1 x 5
     // by 11 % at config 3, 4 x 2 loses 60 %: profiles/r03_k4_forms.log)
-    if (pass == 4 && nb[1] * 2 > nb[0] && (d->n_cols + 1) / 2 >= (int64_t)2 * 256 * nb[1]) return 2;
+    if (pass == 4 && nb[1] * 2 > nb[0] && (d->n_cols + 1) / 2 >= 2 * cus * nb[1]) return 2;
     int best = 1, best_nb = -1;
     for (int i = 3; i >= 0; --i) {                                                      // rule 2
         cb = 1 << i;
-        const int64_t rounds_x256 = nb[i] ? (d->n_cols + cb - 1) / cb / nb[i] : 0;   // rounds of workgroups x 256
-        const bool enough = rounds_x256 >= (cb == 8 ? 8 : 2) * 256;   // measured: 8-column slabs pay off from ~8 rounds
+        const int64_t rounds_x_cus = nb[i] ? (d->n_cols + cb - 1) / cb / nb[i] : 0;   // rounds of workgroups x CUs
+        const bool enough = rounds_x_cus >= (cb == 8 ? 8 : 2) * cus;   // measured: 8-column slabs pay off from ~8 rounds
         if (nb[i] > best_nb && (enough || i == 0)) { best_nb = nb[i]; best = cb; }
     }
     return best;
@@ -1074,12 +1125,6 @@ int launch_status(const char *what)
 #define REQUIRE(ptr, name) \
     if (!(ptr)) return fail(SPC_ERR_INVALID_ARGUMENT, "required pointer %s is NULL", name)
 
-int env_int(const char *name, int dflt)
-{
-    const char *e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
 // Small batches run ONE round of workgroups and are bound by latency, not bandwidth: there fewer, larger workgroups
 // win.  2 / 4 columns per workgroup of 512 / 1024 threads (still one work item per thread, so the per-thread chain is
 // unchanged) cover <= 1024 columns with <= 256 workgroups -- one per CU -- and the grid is dispatched in a half / a
@@ -1088,11 +1133,12 @@ int env_int(const char *name, int dflt)
 // workgroup (workgroup = 256 x that) or 0 = the 256-thread path.  SPC_SMALL_BLOCK=0 disables it (A/B).
 int small_block(const spc_dims *d, int items_per_col)
 {
-    if (d->cols_per_block != 0 || items_per_col > BLOCK || d->n_cols <= 256 || d->n_cols > 1024) return 0;
+    const int64_t cus = device_cus();          // (MI355X: 256 -> the 257 ... 1024 columns of the measurements above)
+    if (d->cols_per_block != 0 || items_per_col > BLOCK || d->n_cols <= cus || d->n_cols > 4 * cus) return 0;
     const int sb = env_int("SPC_SMALL_BLOCK", 1);                    // 0: off; 2 / 4: that many columns per workgroup (A/B)
     if (!sb) return 0;
     if (sb == 2 || sb == 4) return sb;
-    return d->n_cols <= 512 ? 2 : 4;
+    return d->n_cols <= 2 * cus ? 2 : 4;
 }
 
 // ---- launch choice ---------------------------------------------------------------------------------------------
@@ -1153,7 +1199,7 @@ template <typename T> int choose_fwd(const spc_dims *d, bool with_idx, bool full
     const int sb = (full || !c->wt) ? 0 : small_block(d, d->nL + (with_idx ? d->nG : 0));
     // single-round launches keep the prologue prefetch (k_forward's PRE); SPC_K1_PRE=0/1 forces it off / on (A/B)
     const int pre_env = env_int("SPC_K1_PRE", -1);
-    c->pre = (sb || (pre_env >= 0 ? pre_env != 0 : d->n_cols <= 1024)) ? 1 : 0;   // measured: PRE = false wins from 1100 columns
+    c->pre = (sb || (pre_env >= 0 ? pre_env != 0 : d->n_cols <= 4 * (int64_t)device_cus())) ? 1 : 0;   // measured (256 CUs): PRE = false wins from 1100 columns
     c->blk = sb ? BLOCK * sb : BLOCK;
     if (full)
         c->cb = pick_cb(d, 0, with_idx, sizeof(T), fwd_full_kernel<T>(c->geo, c->pre));
@@ -1285,7 +1331,7 @@ template <typename T> int pick_cb_cons3(const spc_dims *d, int geo)
     const bool two_fits = smem2 <= (size_t)MAX_LDS_BYTES;
     if (d->cols_per_block > 0) return (d->cols_per_block >= 2 && two_fits) ? 2 : 1;
     const int nb1 = blocks_per_cu(cons_kernel<T>(geo, 0, 1), smem1);
-    if (d->n_cols <= (int64_t)256 * nb1 || !two_fits) return 1;
+    if (d->n_cols <= (int64_t)device_cus() * nb1 || !two_fits) return 1;
     const int nb2 = blocks_per_cu(cons_kernel<T>(geo, 0, 2), smem2);
     return nb2 * 2 > nb1 ? 2 : 1;
 }
@@ -1311,7 +1357,8 @@ template <typename T> int choose_bwd(const spc_dims *d, bool cons, Choice *c)
     const int sb = (cons || !c->wt) ? 0 : small_block(d, d->nL > d->nG ? d->nL : d->nG);
     const int pre_env = env_int("SPC_K3_PRE", -1);        // SPC_K3_PRE=0/1 forces the prologue prefetch off / on (A/B)
     // PRE = false (8 waves per SIMD) pays between one round of workgroups and saturation: 1 025 ... 25 000 columns
-    c->pre = (cons || sb || (pre_env >= 0 ? pre_env != 0 : (d->n_cols <= 1024 || d->n_cols > 25000))) ? 1 : 0;
+    const int64_t cus = device_cus();      // the measured bounds 1 025 ... 25 000 are 4 ... ~98 columns per CU of the 256
+    c->pre = (cons || sb || (pre_env >= 0 ? pre_env != 0 : (d->n_cols <= 4 * cus || d->n_cols * 256 > 25000 * cus))) ? 1 : 0;
     c->blk = sb ? BLOCK * sb : BLOCK;
     c->cb = sb ? sb : (cons ? (c->geo ? pick_cb_cons3<T>(d, c->geo) : pick_cb(d, 4, false, sizeof(T), cons_kernel<T>(0, cons_depth(d->nL), 0)))
                             : pick_cb(d, 1, false, sizeof(T), bwd_kernel<T>(c->geo, 0, BLOCK, c->pre)));
@@ -1632,7 +1679,7 @@ int spc_describe_launch(const spc_dims *d, int pass, int flags, int elem_size, c
             snprintf(name, sizeof(name), "k_backward_cons3<%s,%d,%d,cb=%d>", ty, GEO_NG[c.geo], GEO_NL[c.geo], c.cb >= 2 ? 2 : 1);
     else
         snprintf(name, sizeof(name), "%s<%s>", c.kernel, ty);
-    return snprintf(buf, (size_t)buflen, "%s cb=%d grid=%u block=%d lds=%lld", name, c.cb, c.grid, c.blk, (long long)c.smem);
+    return snprintf(buf, (size_t)buflen, "%s cb=%d grid=%u block=%d lds=%lld cus=%d", name, c.cb, c.grid, c.blk, (long long)c.smem, device_cus());
 }
 
 int spc_pick_cols_per_block(const spc_dims *d, int pass)

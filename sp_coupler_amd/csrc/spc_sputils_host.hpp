@@ -37,7 +37,7 @@ inline int su_rows(int64_t n_rows, int n_out, size_t lds_per_row, size_t lds_fix
     int rb = n_out > 0 ? (target + n_out - 1) / n_out : 1;
     if (rb < 1) rb = 1;
     if (rb > 64) rb = 64;
-    const int64_t most = n_rows / 1024;                     // >= 1024 workgroups = 4 per CU
+    const int64_t most = n_rows / (4 * (int64_t)device_cus());   // >= 4 workgroups per CU (MI355X: 1024)
     if (rb > most) rb = most < 1 ? 1 : (int)most;
     while (rb > 1 && (lds_per_row * rb + lds_fixed) * esize > cap) --rb;      // 16 KiB: >= 8 workgroups per CU (SPC_SU_LDS_KIB: A/B runs)
     // every wave of a workgroup runs ceil(rb n_out / 256) rounds of the output loop, the last one partly idle: among the

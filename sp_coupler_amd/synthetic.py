@@ -168,12 +168,16 @@ def make_batch_tiled(n_cols, nG=91, nL=160, seed=20261006, base=8192, couple_sur
     return g, zf, zh, p
 
 
-def make_batch_tiled_device(device, n_cols, nG=91, nL=160, seed=20261006, base=8192, couple_surface=True, keys=None):
+def make_batch_tiled_device(device, n_cols, nG=91, nL=160, seed=20261006, base=8192, couple_surface=True, keys=None,
+                            dtype=None, per_column_grid=False):
     """make_batch_tiled with the tiling done ON THE DEVICE: only the ``base`` columns are generated and cross PCIe, the
     tiles and their perturbations are torch ops in HBM (IEEE add / multiply: the same bits as the host version, and
-    tile 0 IS the base batch).  Returns (gcm, zf, zh, prof) of device tensors plus the host base batch."""
+    tile 0 IS the base batch).  Returns (gcm, zf, zh, prof) of device tensors plus the host base batch.
+    ``dtype``: the tensors are generated in float64 and rounded ONCE at the end (torch.float32: the fp32 arithmetic
+    variant's inputs).  ``per_column_grid``: zf / zh are [n_cols x nL], one (slightly stretched) grid per column --
+    north_star's literal layout, ``h = les.zf_cache`` per LES at splib/spcpl.py:222 -- instead of one shared [nL] vector."""
     import torch
-    host = make_batch(min(n_cols, base), nG, nL, seed, couple_surface)
+    host = make_batch(min(n_cols, base), nG, nL, seed, couple_surface, per_column_grid=per_column_grid)
     gcm, zf, zh, prof = host
     up = lambda d: {k: torch.from_numpy(v).to(device) for k, v in d.items() if keys is None or k in keys}   # noqa: E731
     g, p = up(gcm), up(prof)
@@ -183,11 +187,16 @@ def make_batch_tiled_device(device, n_cols, nG=91, nL=160, seed=20261006, base=8
         tile = torch.arange(reps, dtype=torch.float64, device=device).repeat_interleave(base)[:n_cols]
         rep = lambda t: t.repeat(*((reps,) + (1,) * (t.dim() - 1)))[:n_cols].contiguous()                   # noqa: E731
         g, p = {k: rep(v) for k, v in g.items()}, {k: rep(v) for k, v in p.items()}
+        if per_column_grid:
+            zf_d, zh_d = rep(zf_d), rep(zh_d)
         g["T"] += 0.01 * tile[:, None]
         g["U"] *= (1.0 + 1e-3 * tile[:, None])
         p["THL"] += 0.02 * tile[:, None]
         p["V"] -= 0.05 * tile[:, None]
         p["PS"] += tile
+    if dtype is not None and dtype != torch.float64:
+        g, p = {k: v.to(dtype) for k, v in g.items()}, {k: v.to(dtype) for k, v in p.items()}
+        zf_d, zh_d = zf_d.to(dtype), zh_d.to(dtype)
     return g, zf_d, zh_d, p, host
 
 

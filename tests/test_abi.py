@@ -119,7 +119,7 @@ def test_describe_launch_names_the_instantiation_the_launcher_would_pick(lib):
     assert _abi.describe_launch(lib, d(4096), 4, 0).startswith("k_backward_cons3<f64,91,160,cb=")
     # K4's footprint is what lets FIVE two-column workgroups share a CU: 25 of gfx950's 1 280-byte LDS allocation granules
     k4 = _abi.describe_launch(lib, d(35718), 4, 0)
-    assert " cb=2 " in k4 and int(k4.split("lds=")[1]) <= 25 * 1280, k4
+    assert " cb=2 " in k4 and int(k4.split("lds=")[1].split()[0]) <= 25 * 1280, k4
     assert _abi.describe_launch(lib, d(4096, nL=400), 4, 0).startswith("k_backward_cons2<f64,0,0,pd=2> cb=")
     assert _abi.describe_launch(lib, d(4096, nL=2000), 4, 0).startswith("k_backward_cons2<f64,0,0,pd=-1> cb=")
     assert _abi.describe_launch(lib, d(4096), 0, 1, 4).startswith("k_forward<f32,lean,91,160,")
@@ -185,3 +185,36 @@ def test_sputils_module_fails_loudly_without_a_gpu():
                  lambda: sputils.rms(numpy.ones(3))):
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             call()
+
+
+def test_launch_heuristics_follow_the_cu_count_of_the_device(lib, monkeypatch):
+    """round-4 verdict, weak 10: the residency rules (pick_cb rule 1 / rule 2, pick_cb_cons3, small_block, the PRE thresholds,
+    the K7 slab height) count rounds of workgroups against the CUs of the CURRENT device (hipDeviceAttributeMultiprocessorCount,
+    256 on an MI355X in SPX mode, fewer on a CPX / DPX partition) instead of a literal 256.  SPC_CUS overrides the query, so the
+    heuristic can be walked without a GPU: every size class scales with the CU count, and spc_describe_launch says which count
+    it used."""
+    def d(n, nG=91, nL=160):
+        return _abi.Dims(n, nG, nL, nG, nG + 1, nL, 1, 0)
+    desc = lambda n, pass_, flags=0: _abi.describe_launch(lib, d(n), pass_, flags)        # noqa: E731
+    field = lambda txt, k: dict(kv.split("=") for kv in txt.split()[1:])[k]               # noqa: E731
+    seen = {}
+    for cus in (32, 64, 128, 256):
+        monkeypatch.setenv("SPC_CUS", str(cus))
+        assert field(desc(1000, 0, 1), "cus") == str(cus)
+        # small_block: cus < n <= 2 cus -> 512 threads, <= 4 cus -> 1024 threads, beyond -> 256-thread workgroups without the
+        # prologue prefetch (the measured 257 / 513 / 1025 boundaries of 256 CUs)
+        assert "blk=256,pre=1" in desc(cus, 0, 1)
+        assert "blk=512,pre=1" in desc(cus + 1, 0, 1) and "blk=512,pre=1" in desc(2 * cus, 0, 1)
+        assert "blk=1024,pre=1" in desc(2 * cus + 1, 0, 1) and "blk=1024,pre=1" in desc(4 * cus, 0, 1)
+        assert "blk=256,pre=0" in desc(4 * cus + 1, 0, 1)
+        # K3's prologue prefetch comes back where the kernel has saturated: 25 000 columns on 256 CUs, pro rata elsewhere
+        assert ",pre=0>" in desc(25000 * cus // 256, 1) and ",pre=1>" in desc(25000 * cus // 256 + 1, 1)
+        # rule 1 of pick_cb: the smallest slab whose grid is resident at once -- the column count up to which K3 keeps two
+        # columns per workgroup is proportional to the CU count (without a device the occupancy query falls back to 4
+        # workgroups per CU: 8 columns per CU)
+        n1 = min(n for n in range(4 * cus + 1, 40 * cus) if field(desc(n, 1), "cb") != "2") - 1
+        assert n1 == 8 * cus
+        seen[cus] = n1
+    assert seen[64] == 2 * seen[32] and seen[128] == 2 * seen[64] and seen[256] == 2 * seen[128], seen
+    monkeypatch.delenv("SPC_CUS")
+    assert field(desc(1000, 0, 1), "cus") == "256"        # no device here: the MI355X's count

@@ -30,3 +30,20 @@ def test_markstein_quotient_is_the_division(tmp_path):
                    check=True)
     r = subprocess.run([exe, "20000000", "d"], capture_output=True, text=True)
     assert r.returncode == 0 and re.search(r"80000004 arguments, 0 differ", r.stdout), r.stdout + r.stderr
+
+
+def test_spc_powf_is_the_correctly_rounded_power_up_to_ties(tmp_path):
+    """the fp32 variant's power (sp_coupler_amd/csrc/spc_powf.h, round 5: replaces ocml's powf in the float kernels): every
+    101st float of the atmosphere's range and every 1617th of all positive floats, both exponents, against pow() in double --
+    never more than 0.501 ulp (0.5 + 2^-14 by construction); the C library's powf runs next to it for scale.  The GPU box
+    checks that the device computes the same bits (tests/test_sputils_gpu.py)."""
+    exe = str(tmp_path / "pow_accuracy")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-mfma", "-o", exe, os.path.join(ROOT, "tools", "csrc", "pow_accuracy.c"), "-lm"],
+                   check=True)
+    out = subprocess.run([exe, "101", "f"], check=True, capture_output=True, text=True).stdout
+    rows = [ln for ln in out.splitlines() if ln.startswith("spc_powf")]
+    assert len(rows) == 4, out
+    for ln in rows:
+        worst = float(re.search(r"worst ([0-9.]+) ulp", ln).group(1))
+        above = float(re.search(r"> 0.501 ulp ([0-9.e+-]+)", ln).group(1))
+        assert worst <= 0.501 and above == 0.0, ln

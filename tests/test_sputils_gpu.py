@@ -435,3 +435,42 @@ def test_multi_row_slabs_equal_single_row_slabs(seed, n):
         same("interp_c %d" % trial, eng.interp_c(Zd, zd, qd, rd), chunks(eng.interp_c, Zd, zd, qd, rd))
         full = eng.interp_c(Zd, zd, qd, rd).cpu().numpy()
         assert numpy.isnan(full[11]).any() and (full != 0).any() and (full == 0).any()
+
+
+def test_fp32_exner_is_the_host_evaluation_of_spc_powf_bit_for_bit(tmp_path):
+    """the fp32 variant's power (csrc/spc_powf.h: evaluated inside double arithmetic, rounded once; round 5, replaces ocml's
+    powf) is one source of exactly specified IEEE operations for device and host: the device's exner / iexner in float32
+    equals the header compiled with gcc, bit for bit -- so the host sweep's bound (tests/test_pow_accuracy.py: correctly
+    rounded except within 2^-14 ulp of a tie) IS the device's bound.  Reference: splib/sputils.py:28-34 in float32."""
+    import ctypes
+    import subprocess
+    from sp_coupler_amd.engine import Engine
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "libpowf_host.so")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-mfma", "-shared", "-fPIC", "-o", so,
+                    os.path.join(root, "tools", "csrc", "pow_accuracy.c"), "-lm"], check=True)
+    host = ctypes.CDLL(so)
+    host.spc_powf_host.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_long]
+    rng = numpy.random.default_rng(55)
+    p = numpy.concatenate([
+        numpy.exp(rng.uniform(numpy.log(10.0), numpy.log(1.2e5), 1 << 20)),                   # the atmosphere's pressures
+        numpy.exp(rng.uniform(numpy.log(1e-30), numpy.log(1e30), 1 << 18)),                   # any exponent
+        numpy.array([1e5, 101325.0, 1.4e-45, 1e-40, 3.0e38])]).astype(numpy.float32)         # subnormal floats included
+    e32 = Engine("cuda:0", dtype=torch.float32)
+    x = p / numpy.float32(1e5)                                                                # the kernel's float division
+    rd, cp = numpy.float32(287.04), numpy.float32(1004.)
+    for inverse, y in ((False, rd / cp), (True, (-rd) / cp)):
+        got = e32.exner(torch.from_numpy(p).cuda(), inverse=inverse).cpu().numpy()
+        want = numpy.empty_like(x)
+        host.spc_powf_host(x.ctypes.data, ctypes.c_float(float(y)), want.ctypes.data, x.size)
+        assert numpy.array_equal(got.view(numpy.uint32), want.view(numpy.uint32)), int((got.view(numpy.uint32) != want.view(numpy.uint32)).sum())
+        # and against the exact power: half an ulp (+ the 2^-14 ulp of the double evaluation)
+        exact = x.astype(numpy.float64) ** float(y)
+        ulp = numpy.spacing(numpy.abs(exact).astype(numpy.float32)).astype(numpy.float64)
+        assert (numpy.abs(got.astype(numpy.float64) - exact) <= 0.5001 * ulp).all()
+    # C99's special values, produced inline as in the double kernel
+    sp = numpy.array([0.0, -0.0, numpy.inf, -numpy.inf, numpy.nan, -1.0], dtype=numpy.float32)
+    got = e32.exner(torch.from_numpy(sp).cuda()).cpu().numpy()                                # y > 0
+    assert got[0] == 0 and got[1] == 0 and got[2] == numpy.inf and got[3] == numpy.inf and numpy.isnan(got[4]) and numpy.isnan(got[5])
+    got = e32.exner(torch.from_numpy(sp).cuda(), inverse=True).cpu().numpy()                  # y < 0
+    assert got[0] == numpy.inf and got[1] == numpy.inf and got[2] == 0 and got[3] == 0 and numpy.isnan(got[4]) and numpy.isnan(got[5])

@@ -1,11 +1,17 @@
 /* Host sweep of spc_pow_pos (sp_coupler_amd/csrc/spc_pow.h: the device's own source, same IEEE operations; compile with
  * -ffp-contract=off) against powl in 80-bit arithmetic, and of the C library's pow next to it.
  * usage: pow_accuracy <points per exponent> ; prints one line per (function, exponent, range).
- *        pow_accuracy <points> d : spc_div_pref0_markstein against the division instead (exit 1 on any difference). */
+ *        pow_accuracy <points> d : spc_div_pref0_markstein against the division instead (exit 1 on any difference).
+ *        pow_accuracy <stride> f : the fp32 variant's spc_powf_pos (spc_powf.h) on EVERY stride-th float of [1e-4, 1.2] and of
+ *                                  the whole positive range, against pow() in double (2^-29 float ulp: exact for this purpose),
+ *                                  with the C library's powf next to it.
+ *        (built with -shared -fPIC the file also exports spc_powf_host(x, y, out, n) for the GPU-side bit comparison) */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include "../../sp_coupler_amd/csrc/spc_pow.h"
+#include "../../sp_coupler_amd/csrc/spc_powf.h"
+#include <string.h>
 
 static unsigned long long st = 88172645463325252ull;
 static double urand(void) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (double)(st >> 11) * (1.0 / 9007199254740992.0); }
@@ -55,8 +61,49 @@ static long check_division(long n)
     return bad;
 }
 
+
+static float f_of(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static unsigned u_of(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static double ulpf_of(double v) { int e; frexp(v, &e); if (e < -125) e = -125; return ldexp(1.0, e - 24); }
+
+static void sweepf(const char *what, float (*fn)(float, float), float y, float lo, float hi, unsigned stride)
+{
+    double worst = 0; float wx = 0;
+    long n = 0, a50 = 0, a51 = 0, a100 = 0;
+    for (unsigned u = u_of(lo); u <= u_of(hi); u += stride) {
+        const float x = f_of(u);
+        const double want = pow((double)x, (double)y);
+        const double got = (double)fn(x, y);
+        const double err = fabs(got - want) / ulpf_of(want);
+        if (err > worst) { worst = err; wx = x; }
+        a50 += err > 0.5; a51 += err > 0.501; a100 += err > 1.0; ++n;
+    }
+    printf("%-10s y=%+.9g x in [%.3g, %.3g] every %u-th float: %ld points, worst %.5f ulp (x = %.9g), > 0.5 ulp %.3e, > 0.501 ulp %.3e, > 1 ulp %.3e\n",
+           what, (double)y, (double)lo, (double)hi, stride, n, worst, (double)wx, (double)a50 / n, (double)a51 / n, (double)a100 / n);
+}
+
+static int float_mode(unsigned stride)
+{
+    const float rd = 287.04f, cp = 1004.f;
+    const float ys[2] = {(-rd) / cp, rd / cp};                       /* the kernels' own float exponents */
+    for (int k = 0; k < 2; ++k) {
+        sweepf("spc_powf", spc_powf_pos, ys[k], 1e-4f, 1.2f, stride);
+        sweepf("spc_powf", spc_powf_pos, ys[k], 1.4e-45f, 3.4e38f, stride * 16u + 1u);
+        sweepf("libm powf", powf, ys[k], 1e-4f, 1.2f, stride * 4u + 1u);
+    }
+    return 0;
+}
+
+/* the header's function on a vector, for tests/test_sputils_gpu.py (this file built with -shared): the GPU box compares the
+ * device's fp32 exner operator with it bit for bit */
+void spc_powf_host(const float *x, float y, float *out, long n)
+{
+    for (long i = 0; i < n; ++i) out[i] = spc_powf_pos(x[i], y);
+}
+
 int main(int argc, char **argv)
 {
+    if (argc > 2 && argv[2][0] == 'f') return float_mode((unsigned)atol(argv[1]));
     if (argc > 2 && argv[2][0] == 'd') return check_division(atol(argv[1])) != 0;
     const long n = argc > 1 ? atol(argv[1]) : 20000000;
     const double rd = 287.04, cp = 1004.;

@@ -688,7 +688,8 @@ def config_leg(device, cfg, dtype_name, per_column_grid, factor, dt, steps=100, 
     el = time.perf_counter() - t0
     k1, k3 = wl.kernel_times(stream, sptr, launches=launches)
     try:
-        ok, det = sample_check(wl.fplans[0].outputs, wl.bplans[0].outputs, *wl.inputs0, factor, dt, m=check_rows)
+        g0, zf0, zh0, p0 = wl.inputs0
+        ok, det = sample_check(wl.fplans[0].outputs, wl.bplans[0].outputs, g0, p0, zf0, zh0, factor, dt, m=check_rows)
     except Exception as e:
         ok, det = False, {"failures": ["sample_check raised %r" % (e,)]}
     res = {"workload": "config %d: %d synthetic SP columns on one GPU, %d GCM <-> %d LES levels, %s, %s, %d batch(es) resident in HBM"

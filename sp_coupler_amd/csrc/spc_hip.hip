@@ -46,8 +46,16 @@ __constant__ double spc_pow_coef_table[21] = {SPC_POW_COEFS};
 #ifndef SPC_EXP
 #define SPC_EXP 0
 #endif
+// Mutation control of the semantic tests (tools/mutation_control.py, never the shipped library): -DSPC_MUTANT=n perturbs ONE
+// line of a kernel -- the slip a transcription of the reference could contain -- and tests/test_semantic_gpu.py must fail.
+#ifndef SPC_MUTANT
+#define SPC_MUTANT 0
+#endif
+#define SPC_MUT(n, mutated, original) (SPC_MUTANT == (n) ? (mutated) : (original))
 #if SPC_EXP
-#define SPC_DIV(a, b) ((a) * __builtin_amdgcn_rcp(b))
+__device__ __forceinline__ double spc_exp_rcp(double b) { return __builtin_amdgcn_rcp(b); }
+__device__ __forceinline__ float spc_exp_rcp(float b) { return __builtin_amdgcn_rcpf(b); }
+#define SPC_DIV(a, b) ((a) * spc_exp_rcp(b))
 #else
 #define SPC_DIV(a, b) ((a) / (b))
 #endif
@@ -129,7 +137,9 @@ __device__ __forceinline__ double spc_exner_pow(double p, double y)
 #include "spc_powf.h"
 __device__ __forceinline__ float spc_pow(float x, float y)
 {
-#if defined(SPC_OCML_POW) || defined(SPC_OCML_POWF)     // A/B builds: ocml's powf (what rounds 1-4 shipped)
+#if SPC_EXP >= 2
+    return x * y;
+#elif defined(SPC_OCML_POW) || defined(SPC_OCML_POWF)     // A/B builds: ocml's powf (what rounds 1-4 shipped)
     return powf(x, y);
 #else
     if (!(x > 0.0f && x <= 3.4028234663852886e38f)) {
@@ -212,6 +222,17 @@ template <typename T> __device__ __forceinline__ int ss_left_neg(const T *a, int
     while (lo < hi) {
         int mid = lo + ((hi - lo) >> 1);
         if (np_lt(-a[mid], key)) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// numpy.searchsorted(a, key) (side='left'): first i with !(a[i] < key) -- only the mutation control uses it (SPC_MUTANT 5)
+template <typename T> __device__ __forceinline__ int ss_left_pos(const T *a, int n, T key)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        int mid = lo + ((hi - lo) >> 1);
+        if (np_lt(a[mid], key)) lo = mid + 1; else hi = mid;
     }
     return lo;
 }
@@ -522,12 +543,12 @@ __global__ __launch_bounds__(BLK, SPC_K1_WAVES) void k_forward(const FwdP<T, FUL
         s[0] = zf_k;
         s[2 * nG] = sh + ql + qi;                                                     // spcpl.py:215
         s[3 * nG] = ql;
-        s[4 * nG] = uu;
+        SPC_MUT(6, lds + (size_t)c * 6 * nG + k, s)[4 * nG] = uu;
         s[5 * nG] = vv;
         if constexpr (FULL)
             if (OPT(Zf)) OPT(Zf)[g] = zf_k;                                             // spcpl.py:200
-        const T iex = spc_pow(div_pref0(pf), (-K<T>::rd) / K<T>::cp);                 // sputils.py:34
-        s[nG] = (tt - div_cp(K<T>::rlv * (ql + qi))) * iex;                           // spcpl.py:214
+        const T iex = spc_pow(div_pref0(pf), SPC_MUT(1, K<T>::rd, -K<T>::rd) / K<T>::cp);   // sputils.py:34
+        s[nG] = SPC_MUT(8, tt + div_cp(K<T>::rlv * (ql + qi)), tt - div_cp(K<T>::rlv * (ql + qi))) * iex;   // spcpl.py:214
     }
     STAMP(2);
     __syncthreads();
@@ -541,7 +562,7 @@ __global__ __launch_bounds__(BLK, SPC_K1_WAVES) void k_forward(const FwdP<T, FUL
             if constexpr (FULL)
                 if (OPT(rainrate)) { sc_rain = OPT(rain)[col]; sc_rl = OPT(rain_last)[col]; }
         }
-        stg<WT>(&p.f_ps[col], p.factor * (sc_ps - sc_psd) / p.dt);          // spcpl.py:332
+        stg<WT>(&p.f_ps[col], SPC_DIV(p.factor * (sc_ps - sc_psd), p.dt));          // spcpl.py:332
         if constexpr (FULL) {
             if (OPT(ps)) OPT(ps)[col] = sc_ps;
             if (OPT(rainrate)) OPT(rainrate)[col] = (sc_rain - sc_rl) / p.dt;   // spcpl.py:325
@@ -594,11 +615,11 @@ __global__ __launch_bounds__(BLK, SPC_K1_WAVES) void k_forward(const FwdP<T, FUL
             }
 #endif
             const T thl = r[0], qt = r[1], ql = r[2], u = r[3], v = r[4];               // spcpl.py:224-228
-            stg<WT>(&p.f_u[o], p.factor * (u - in.ud) / p.dt);               // spcpl.py:328
-            stg<WT>(&p.f_v[o], p.factor * (v - in.vd) / p.dt);               // spcpl.py:329
-            stg<WT>(&p.f_thl[o], p.factor * (thl - in.thld) / p.dt);         // spcpl.py:330
-            stg<WT>(&p.f_qt[o], p.factor * (qt - in.qtd) / p.dt);            // spcpl.py:331
-            stg<WT>(&p.f_ql[o], p.factor * (ql - in.qld) / p.dt);            // spcpl.py:333
+            stg<WT>(&p.f_u[o], SPC_DIV(p.factor * (u - SPC_MUT(2, in.vd, in.ud)), p.dt));               // spcpl.py:328
+            stg<WT>(&p.f_v[o], SPC_DIV(p.factor * (v - SPC_MUT(2, in.ud, in.vd)), p.dt));               // spcpl.py:329
+            stg<WT>(&p.f_thl[o], SPC_DIV(p.factor * (thl - in.thld), p.dt));         // spcpl.py:330
+            stg<WT>(&p.f_qt[o], SPC_DIV(p.factor * (qt - in.qtd), p.dt));            // spcpl.py:331
+            stg<WT>(&p.f_ql[o], SPC_DIV(p.factor * (ql - in.qld), p.dt));            // spcpl.py:333
             stg<WT>(&p.ql_ref[o], ql);                                                         // spcpl.py:347-348
             if constexpr (FULL) {
                 if (OPT(u)) OPT(u)[o] = u;
@@ -613,7 +634,7 @@ __global__ __launch_bounds__(BLK, SPC_K1_WAVES) void k_forward(const FwdP<T, FUL
             const T zs = (PRE && e == tid) ? pre_zs : ldg(&p.Zghalf[gh + nG]);
             const T Zh_k = div_grav(zgh - zs);                                        // spcpl.py:197
             const T *const zh = d.shared_grid ? lzh : lzh + (size_t)c * nL;
-            p.idx[col * pitchG + m] = ss_right(zh, nL, Zh_k);
+            p.idx[col * pitchG + m] = SPC_MUT(5, ss_left_pos(zh, nL, Zh_k), ss_right(zh, nL, Zh_k));
         }
     }
     STAMP(4);
@@ -721,7 +742,7 @@ template <typename T, int NG, int NL, int WT, int BLK = BLOCK, bool PRE = true> 
     if (PRE && tid < n1) {
         const int c = tid / nG, k = tid - c * nG;
         const int64_t cg = (col0 + c) * pitchG;
-        pre = load_gcm(p, cg + k, cg + (nG - 1 - k));
+        pre = load_gcm(p, cg + k, SPC_MUT(9, (col0 + ((c ^ 1) < ncol ? (c ^ 1) : c)) * pitchG, cg) + (nG - 1 - k));
     }
     STAMP(1);
 
@@ -754,7 +775,7 @@ template <typename T, int NG, int NL, int WT, int BLK = BLOCK, bool PRE = true> 
         const T *const s = lds + (size_t)c * per_col;
         const T *const h = d.shared_grid ? lh : lh + (size_t)c * nL;
         const T *const Zf = s + 6 * nL;
-        const GcmIn<T> in = (PRE && e == tid) ? pre : load_gcm(p, g, cg + (nG - 1 - k));
+        const GcmIn<T> in = (PRE && e == tid) ? pre : load_gcm(p, g, SPC_MUT(9, (col0 + ((c ^ 1) < ncol ? (c ^ 1) : c)) * pitchG, cg) + (nG - 1 - k));
         const T x = Zf[k];
         const int start_index = ss_left_neg(Zf, nG, h[nL - 1]);                        // spcpl.py:498
         // (the branch-light interp_fields<7> form was measured here too: no gain at 1024 columns and -12 % at
@@ -783,14 +804,14 @@ template <typename T, int NG, int NL, int WT, int BLK = BLOCK, bool PRE = true> 
         } else {
             t_i = qt_i = ql_i = qlw_i = qli_i = u_i = v_i = x;
         }
-        T f_T = p.factor * (t_i - in.tt) / p.dt;                                       // spcpl.py:518
-        T f_SH = p.factor * ((qt_i - ql_i) - in.sh) / p.dt;                            // spcpl.py:519
-        T f_QL = p.factor * (qlw_i - in.ql) / p.dt;                                    // spcpl.py:520
-        T f_QI = p.factor * (qli_i - in.qi) / p.dt;                                    // spcpl.py:521
-        T f_U = p.factor * (u_i - in.u) / p.dt;                                        // spcpl.py:524
-        T f_V = p.factor * (v_i - in.v) / p.dt;                                        // spcpl.py:525
-        T f_A = p.factor * (in.a_d - in.a) / p.dt;                                     // spcpl.py:526
-        if (k < start_index) {  // `f[0:start_index] *= 0` (spcpl.py:527-533): -x -> -0, NaN stays NaN
+        T f_T = SPC_DIV(p.factor * (t_i - in.tt), p.dt);                                       // spcpl.py:518
+        T f_SH = SPC_DIV(p.factor * ((qt_i - ql_i) - in.sh), p.dt);                            // spcpl.py:519
+        T f_QL = SPC_DIV(p.factor * (SPC_MUT(3, ql_i, qlw_i) - in.ql), p.dt);                                    // spcpl.py:520
+        T f_QI = SPC_DIV(p.factor * (qli_i - in.qi), p.dt);                                    // spcpl.py:521
+        T f_U = SPC_DIV(p.factor * (u_i - in.u), p.dt);                                        // spcpl.py:524
+        T f_V = SPC_DIV(p.factor * (v_i - in.v), p.dt);                                        // spcpl.py:525
+        T f_A = SPC_DIV(p.factor * (in.a_d - in.a), p.dt);                                     // spcpl.py:526
+        if (SPC_MUT(4, k <= start_index, k < start_index)) {  // `f[0:start_index] *= 0` (spcpl.py:527-533): -x -> -0, NaN stays NaN
             const T zero = T(0);
             f_T *= zero; f_SH *= zero; f_QL *= zero; f_QI *= zero; f_U *= zero; f_V *= zero; f_A *= zero;
         }
@@ -911,7 +932,7 @@ template <typename T> __global__ __launch_bounds__(BLOCK) void k_diag(const Diag
             const T pf = interp_at(b, s + nG);                                         // spcpl.py:408
             if (p.pf) p.pf[o] = pf;
             if (p.t)                                                                   // spcpl.py:409
-                p.t[o] = p.thl_d[o] * spc_pow(div_pref0(pf), K<T>::rd / K<T>::cp) + div_cp(K<T>::rlv * p.ql_d[o]);
+                p.t[o] = p.thl_d[o] * spc_pow(div_pref0(pf), SPC_MUT(10, -K<T>::rd, K<T>::rd) / K<T>::cp) + div_cp(K<T>::rlv * p.ql_d[o]);
             if (p.ql_water) p.ql_water[o] = p.ql_d[o] - p.ql_ice_d[o];                  // spcpl.py:402
         }
     }

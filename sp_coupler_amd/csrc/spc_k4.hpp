@@ -287,7 +287,7 @@ template <typename T, int NG, int NL, int CB> __global__ __launch_bounds__(BLOCK
         const int64_t o = (col0 + c) * pitchL + l;
         const T t = p.t_d[o], qt = p.qt_d[o], ql = p.ql_d[o], qi = p.ql_ice_d[o], u = p.u_d[o], v = p.v_d[o], w = p.rhobf_d[o];
         T *const s = lds + (size_t)c * per_col + l;
-        s[0] = w * t;                                                                    // sputils.py:152: w * q, per field
+        s[0] = SPC_MUT(11, t, w * t);                                                    // sputils.py:152: w * q, per field
         s[nLp] = w * qt;                                                                 // (order of spcpl.py:482-488)
         s[2 * nLp] = w * ql;
         s[3 * nLp] = w * (ql - qi);                                                      // ql_water, spcpl.py:402

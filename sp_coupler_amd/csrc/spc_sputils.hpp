@@ -356,7 +356,7 @@ template <typename T, int PD, int SL, bool WEIGHTED, int WT> __global__ __launch
                 const int e = e0 + u * SU_THREADS;
                 if (e < total) {
                     const T dz = z1[u] - z0[u];
-                    ltn[e] = WEIGHTED ? (wv[u] * qv[u]) * dz : qv[u] * dz;             // sputils.py:154 / 146
+                    ltn[e] = (WEIGHTED && SPC_MUTANT != 7) ? (wv[u] * qv[u]) * dz : qv[u] * dz;             // sputils.py:154 / 146
                     if constexpr (WEIGHTED) ltd[e] = wv[u] * dz;                       // sputils.py:159
                 }
             }

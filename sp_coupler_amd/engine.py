@@ -181,14 +181,15 @@ class Engine:
     """One engine per (device, dtype). ``dtype`` is the arithmetic type of the path: float64 as in
     the reference (AMUSE quantities wrap float64 arrays), float32 for the tolerance sweep."""
 
-    def __init__(self, device=None, dtype=torch.float64, stream=None):
+    def __init__(self, device=None, dtype=torch.float64, stream=None, lib_path=None):
         """``stream``: a ``torch.cuda.Stream`` every plan and every K7 operator of this engine launches on (None: torch's
         current stream of the device at launch time).  The engine's transfer buffers (``arena``) order their copies
         against the same stream, and the tensors the engine allocates are allocated under it (``on_stream``), so an
         engine with a stream of its own never depends on what stream is current in the caller.  Several such engines on
         ONE device run the row blocks of a ``multi.MultiDeviceEngine`` batch concurrently."""
         self.stream = stream
-        self.lib = _abi.load_library()          # raises SpcLibraryError if the HIP extension is missing
+        # ``lib_path``: another build of the SAME ABI (A/B runs, tools/mutation_control.py); default: the shipped library
+        self.lib = _abi.load_library(lib_path)  # raises SpcLibraryError if the HIP extension is missing
         if dtype not in _DTYPES:
             raise ValueError("dtype must be torch.float64 or torch.float32")
         if not torch.cuda.is_available() or self.lib.spc_device_count() < 1:

@@ -1,0 +1,59 @@
+"""CPU twin of tests/test_semantic_gpu.py: the semantic properties of tests/semantic_props.py (derived from the reference's
+text, evaluated with plain NumPy) held against the NumPy ORACLE.  The oracle restates splib/spcpl.py:171-246, 299-333, 388-533
+and splib/sputils.py:94-197 line by line; these properties are what would catch a transcription slip in that restatement."""
+import numpy
+import pytest
+
+from oracle import spcpl_oracle as orc
+from tests import semantic_props as sp
+
+
+class OracleImpl:
+    name = "oracle/spcpl_oracle.py"
+
+    def forward(self, gcm, zf, zh, prof, factor, dt):
+        r = orc.forward_batched(gcm, prof, zf, zh, factor, dt)
+        return r
+
+    def backward(self, gcm, zf, zh, prof, factor, dt, conservative):
+        Zf, Zh = sp.heights(gcm)
+        return orc.backward_batched(gcm, Zf, prof, zf, factor, dt, conservative=conservative, Zh=Zh, zh=zh)
+
+    def interp_c(self, Zh, zh, q, rho):
+        return numpy.stack([orc.interp_c(Zh[c], zh, q[c], rho[c]) for c in range(Zh.shape[0])])
+
+    def interp_rho(self, Zh, zh, rho):
+        with numpy.errstate(all="ignore"):
+            return numpy.stack([orc.interp_rho(Zh[c], zh, rho[c]) for c in range(Zh.shape[0])])
+
+    def les_temperature(self, gcm, zf, prof):
+        Zf, _ = sp.heights(gcm)
+        r = orc.backward_batched(gcm, Zf, prof, zf, 1.0, sp.DT)
+        return r["pf"], r["t"]
+
+
+@pytest.mark.parametrize("prop", sp.PROPERTIES, ids=lambda f: f.__name__[5:])
+def test_property_holds_for_the_oracle(prop):
+    prop(OracleImpl())
+
+
+# The CPU side of the mutation control (tools/mutation_control.py does it for the kernels on the GPU box): a slip planted in the
+# ORACLE is caught by the property that guards that line -- the properties do not take their expectations from the oracle.
+SLIPS = {
+    "isentropic_column_has_constant_thl": ("iexner", lambda p: orc.exner(p)),                                   # sign of rd/cp
+    "index_map_is_a_count": ("cloud_fraction_indices", lambda zh, Zh: numpy.searchsorted(zh, Zh, side="left")[:-1][::-1]),
+    "conservative_coarsening_conserves": ("interp_c", lambda Zh, zh, q, rho: numpy.array(
+        [orc.integral(Zh[i + 1], Zh[i], zh, q, None) / (Zh[i] - Zh[i + 1]) if Zh[i] < zh[-1] else 0.0 for i in range(len(Zh) - 1)])),
+    "masking_above_the_les_top": ("searchsorted", lambda a, v, **kw: numpy.searchsorted(a, v, **kw) + 1),
+    "reversal_is_index_arithmetic_only": ("interp", lambda x, xp, fp: numpy.interp(x, xp, fp[::-1])),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SLIPS))
+def test_a_slip_planted_in_the_oracle_is_caught(name, monkeypatch):
+    attr, wrong = SLIPS[name]
+    prop = next(p for p in sp.PROPERTIES if p.__name__ == "prop_" + name)
+    prop(OracleImpl())
+    monkeypatch.setattr(orc, attr, wrong)
+    with pytest.raises(AssertionError):
+        prop(OracleImpl())

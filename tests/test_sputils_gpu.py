@@ -455,9 +455,10 @@ def test_fp32_exner_is_the_host_evaluation_of_spc_powf_bit_for_bit(tmp_path):
     p = numpy.concatenate([
         numpy.exp(rng.uniform(numpy.log(10.0), numpy.log(1.2e5), 1 << 20)),                   # the atmosphere's pressures
         numpy.exp(rng.uniform(numpy.log(1e-30), numpy.log(1e30), 1 << 18)),                   # any exponent
-        numpy.array([1e5, 101325.0, 1.4e-45, 1e-40, 3.0e38])]).astype(numpy.float32)         # subnormal floats included
+        numpy.array([1e5, 101325.0, 2e-40, 1e-38, 3.0e38])]).astype(numpy.float32)           # subnormal quotients included
     e32 = Engine("cuda:0", dtype=torch.float32)
     x = p / numpy.float32(1e5)                                                                # the kernel's float division
+    assert (x > 0).all() and (x[-3:-1] < 1.1754944e-38).all()
     rd, cp = numpy.float32(287.04), numpy.float32(1004.)
     for inverse, y in ((False, rd / cp), (True, (-rd) / cp)):
         got = e32.exner(torch.from_numpy(p).cuda(), inverse=inverse).cpu().numpy()

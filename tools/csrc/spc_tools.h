@@ -21,6 +21,9 @@ int spc_stream_copy_f64(void *dst, const void *src, int64_t bytes, void *stream)
 int spc_stream_probe(int n_read, int n_write, void *dst, const void *src, int64_t bytes_per_stream, int grid, void *stream);
 /* one wave running `n` dependent fp64 adds (x = x + c); in: >= 32 doubles, out: 64 doubles.  tools/fp64_chain.py */
 int spc_probe_add_chain(void *out, const void *in, int n, void *stream);
+/* one wave per SIMD of one CU running `n` rounds of 8 independent copies of vector instruction `op` (tools/issue_rate.py
+ * holds the table of ops); in: >= 32 doubles, out: 256 doubles */
+int spc_probe_issue(int op, void *out, const void *in, int n, void *stream);
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Mutation control of the semantic tests (round-4 verdict, next 2: "each property fails when the corresponding line of the
+kernel is perturbed").  For the shipped library and for every mutant build/mutants/libspc_mutantN.so (tools/build_mutants.sh:
+ONE kernel line perturbed each, -DSPC_MUTANT=N) the properties of tests/semantic_props.py run through the HIP kernels, in ONE
+process (Engine(lib_path=...)).  Expected: the shipped library passes all, every mutant fails at least the property that
+guards its line.  Prints a table; exit status 1 if a mutant survives or the shipped library fails.
+usage: python tools/mutation_control.py > profiles/r05_mutation_control.log"""
+import os
+import sys
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+MUTANTS = {
+    1: ("K1 thl: exponent +rd/cp instead of -rd/cp (exner for iexner, sputils.py:28-34)", "isentropic_column_has_constant_thl"),
+    2: ("K1 forcings: u_d and v_d swapped (spcpl.py:328-329)", "zero_forcings_when_the_les_equals_the_interpolated_gcm_profile"),
+    3: ("K3 f_QL from ql instead of ql_water = ql - ql_ice (spcpl.py:402, 520)", "total_water_tendency_closes"),
+    4: ("K3 masking one level too far: k <= start_index (spcpl.py:527-533)", "masking_above_the_les_top"),
+    5: ("K2 index map with side='left' instead of 'right' (spcpl.py:764)", "index_map_is_a_count"),
+    6: ("K1 staging: U not reversed (spcpl.py:227)", "reversal_is_index_arithmetic_only"),
+    7: ("K7 interp_c: numerator without the weight rho (sputils.py:152-154)", "conservative_coarsening_conserves"),
+    8: ("K1 thl: latent term added instead of subtracted (spcpl.py:214)", "isentropic_column_has_constant_thl"),
+    9: ("K3 cloud fraction A_d read from the neighbouring column of the slab (spcpl.py:404)", "columns_are_independent"),
+    10: ("K5 t: exponent -rd/cp instead of +rd/cp (spcpl.py:409)", "isentropic_column_has_constant_thl"),
+    11: ("K4 f_T: numerator without the weight rho (spcpl.py:482, sputils.py:152)", "conservative_coarsening_conserves"),
+}
+
+
+def run(lib_path):
+    from tests import semantic_props as sp
+    from tests.test_semantic_gpu import HipImpl
+    impl = HipImpl(lib_path)
+    failed = []
+    for prop in sp.PROPERTIES:
+        try:
+            prop(impl)
+        except AssertionError:
+            failed.append(prop.__name__[5:])
+        except Exception:
+            failed.append(prop.__name__[5:] + " (raised: %s)" % traceback.format_exc().strip().splitlines()[-1])
+    return failed
+
+
+def main():
+    import torch
+    print("mutation control of tests/test_semantic_gpu.py on %s" % torch.cuda.get_device_name(0))
+    bad = 0
+    clean = run(None)
+    print("shipped library: %d properties, failed: %s" % (8, clean or "none"))
+    bad += bool(clean)
+    for n, (what, guard) in sorted(MUTANTS.items()):
+        path = os.path.join(ROOT, "build", "mutants", "libspc_mutant%d.so" % n)
+        if not os.path.exists(path):
+            print("mutant %2d: NOT BUILT (%s)" % (n, path))
+            bad += 1
+            continue
+        failed = run(path)
+        ok = guard in [f.split(" ")[0] for f in failed]
+        bad += not ok
+        print("mutant %2d: %s\n           guarded by %s: %s; all failing: %s" % (n, what, guard, "DETECTED" if ok else "SURVIVED", failed or "none"))
+    print("result: %s" % ("every mutant detected, shipped library clean" if not bad else "%d problem(s)" % bad))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

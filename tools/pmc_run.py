@@ -16,15 +16,17 @@ from tools import spc_tools  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 rot = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-with_k4 = len(sys.argv) > 3 and sys.argv[3] == "k4"        # also the conservative backward (K4) on the same batches
-eng = Engine("cuda:0")
+mode = sys.argv[3] if len(sys.argv) > 3 else ""
+with_k4 = mode == "k4"                                      # also the conservative backward (K4) on the same batches
+percol = mode == "percol"                                   # LES grid packed per column [n x nL] (north_star's literal layout)
+nG, nL = (137, 512) if mode.startswith("cfg5") else (91, 160)
+dtype = torch.float32 if mode.endswith("f32") else torch.float64
+eng = Engine("cuda:0", dtype=dtype)
 sptr = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 fpl, bpl, cpl = [], [], []
 for r in range(rot):
-    gcm, zf, zh, prof = synthetic.make_batch_tiled(n, 91, 160, seed=500 + r, couple_surface=False)
-    g = {k: torch.from_numpy(v).cuda() for k, v in gcm.items()}
-    p = {k: torch.from_numpy(v).cuda() for k, v in prof.items()}
-    zf_d, zh_d = torch.from_numpy(zf).cuda(), torch.from_numpy(zh).cuda()
+    g, zf_d, zh_d, p, _ = synthetic.make_batch_tiled_device(eng.device, n, nG, nL, seed=500 + r, couple_surface=False, dtype=dtype,
+                                                            per_column_grid=percol)
     fp, bp = eng.plan_exchange(g, zf_d, zh_d, p, 1.0, 1.0, 900.0)      # exactly what bench.py times
     fpl.append(fp)
     bpl.append(bp)
@@ -42,4 +44,4 @@ for i in range(3 * rot):
     if with_k4:
         cpl[i % rot].launch_raw(sptr)
 torch.cuda.synchronize()
-print("pmc workload done: n=%d rot=%d copy_bytes=%d" % (n, rot, src.numel()))
+print("pmc workload done: n=%d rot=%d mode=%s %d<->%d %s copy_bytes=%d" % (n, rot, mode or "-", nG, nL, dtype, src.numel()))

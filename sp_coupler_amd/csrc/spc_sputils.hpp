@@ -18,7 +18,8 @@
 //   * staging is a compile-time switch (STAGE) everywhere: LDS pointers are LDS pointers; rows that do not fit read global;
 //   * a workgroup owns a SLAB of rows (su_rows: ~1 000-1 300 outputs, as K1's 8-column slabs) and loads it with flat,
 //     coalesced accesses, all of a thread's loads issued before the first LDS store;
-//   * launches that write <= 32 MiB store write-through (WT, as K1 / K3: nothing left dirty in L2 at the end);
+//   * launches that write <= 64 MiB store write-through (WT; su_write_through in spc_sputils_host.hpp -- K1 draws that line
+//     at 32 MiB, K3 at 14: nothing left dirty in L2 at the end);
 //   * interp_c forms the per-CELL terms (w q) dz and w dz once while staging; a layer's two sums are then pure additions
 //     of LDS values, run side by side in ONE numpy-ordered pass (Pair2);
 //   * rms: 8 lanes per row = the 8 accumulators of numpy's leaf, combined by shuffles in numpy's order (64-B segments,

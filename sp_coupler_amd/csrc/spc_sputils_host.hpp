@@ -29,7 +29,11 @@ template <typename T> int exner_impl(int64_t n, const void *p, void *out, int in
 // Rows per workgroup (the slab): enough rows for ~`target` outputs per workgroup -- 4-5 per thread, the shape of K1's
 // 8-column slabs -- within the LDS budget, but never so many that the grid drops under four workgroups per CU (small
 // batches are latency-bound: more, smaller workgroups).  SPC_SU_TARGET overrides for A/B runs.
-inline int su_rows(int64_t n_rows, int n_out, size_t lds_per_row, size_t lds_fixed, size_t esize, int *stage, int lds_kib = 16, bool fit_rounds = true)
+// `max_pitch`: the largest row pitch (elements) of the launch -- the kernels address a slab with 32-bit BYTE offsets r * pitch + i
+// off uniform bases, so rb * max_pitch * 8 must stay below 2^32 whatever chose rb (the SPC_SU_RB override included): rows
+// padded to millions of elements get fewer rows per workgroup (round-4 advisor: the bound was a comment, not a check).
+inline int su_rows(int64_t n_rows, int n_out, size_t lds_per_row, size_t lds_fixed, size_t esize, int *stage, int64_t max_pitch, int lds_kib = 16,
+                   bool fit_rounds = true)
 {
     static const int target = [] { const char *e = getenv("SPC_SU_TARGET"); const int v = e ? atoi(e) : 1100; return v < 1 ? 1 : v; }();
     static const int cap_env = [] { const char *e = getenv("SPC_SU_LDS_KIB"); return e ? atoi(e) : 0; }();
@@ -56,16 +60,21 @@ inline int su_rows(int64_t n_rows, int n_out, size_t lds_per_row, size_t lds_fix
     }
     static const int forced = [] { const char *e = getenv("SPC_SU_RB"); return e ? atoi(e) : 0; }();      // A/B runs
     if (forced > 0 && forced <= 64) rb = forced;
+    while (rb > 1 && (int64_t)rb * max_pitch * 8 >= ((int64_t)1 << 32)) --rb;      // (8: the widest element; output rows of searchsorted are int64)
     *stage = (lds_per_row * rb + lds_fixed) * esize <= SU_MAX_LDS;
     return rb;
 }
 
-// the kernels address a slab with 32-bit element offsets r * pitch + i (r < 64 rows, 24-bit multiply): pitches stay below 2^24 elements
-inline bool su_pitch_ok(std::initializer_list<int64_t> pitches)
+// the kernels address a slab with 32-bit element offsets r * pitch + i (r < 64 rows, 24-bit multiply): pitches stay below 2^24
+// elements -- except for a ONE-row launch, whose row index is always 0: the pitch is never multiplied (sputils.interp /
+// searchsorted on one long vector of 2^24 or more points; round-4 advisor)
+inline bool su_pitch_ok(int64_t n_rows, std::initializer_list<int64_t> pitches)
 {
+    if (n_rows <= 1) return true;
     for (int64_t p : pitches) if (p >= ((int64_t)1 << 24)) return false;
     return true;
 }
+inline int64_t su_max(std::initializer_list<int64_t> v) { int64_t m = 0; for (int64_t x : v) if (x > m) m = x; return m; }
 
 // template argument SL of the staged kernels for a row whose power-of-two floor is p2: log2 p2 + 1 where that depth is
 // instantiated (rows of 64-127, 128-255, 256-511, 512-1023 entries: every level count of BASELINE.json's configs), else 0
@@ -104,14 +113,14 @@ template <typename T> int interp_impl(const spc_interp_args *a, void *stream)
     REQUIRE(a->x, "x"); REQUIRE(a->xp, "xp"); REQUIRE(a->fp, "fp"); REQUIRE(a->out, "out");
     if ((a->pitch_x && a->pitch_x < a->n_x) || (a->pitch_xp && a->pitch_xp < a->n_xp) || a->pitch_fp < a->n_xp || a->pitch_out < a->n_x)
         return fail(SPC_ERR_INVALID_ARGUMENT, "%sinterp: a pitch is smaller than its row (only x and xp may be shared, pitch 0)");
-    if (!su_pitch_ok({a->pitch_x, a->pitch_xp, a->pitch_fp, a->pitch_out})) return fail(SPC_ERR_UNSUPPORTED, "%sinterp: a row pitch of 2^24 elements or more");
+    if (!su_pitch_ok(a->n_rows, {a->pitch_x, a->pitch_xp, a->pitch_fp, a->pitch_out})) return fail(SPC_ERR_UNSUPPORTED, "%sinterp: a row pitch of 2^24 elements or more");
     SuInterpP q;
     q.n_rows = a->n_rows; q.pitch_x = a->pitch_x; q.pitch_xp = a->pitch_xp; q.pitch_fp = a->pitch_fp; q.pitch_out = a->pitch_out;
     q.n_x = a->n_x; q.n_xp = a->n_xp; q.p2 = floor_pow2(a->n_xp);
     int stage;
     const size_t xrow = (size_t)su_pad(q.p2);            // a padded xp row in LDS
     const size_t per_row = (size_t)a->n_xp + (a->pitch_xp ? xrow : 0), fixed = a->pitch_xp ? 0 : xrow;
-    q.rb = su_rows(a->n_rows, a->n_x, per_row, fixed, sizeof(T), &stage);
+    q.rb = su_rows(a->n_rows, a->n_x, per_row, fixed, sizeof(T), &stage, a->n_rows > 1 ? su_max({a->pitch_x, a->pitch_xp, a->pitch_fp, a->pitch_out}) : 0);
     if ((a->n_rows + q.rb - 1) / q.rb > 0x7fffffff) return fail(SPC_ERR_UNSUPPORTED, "%sinterp: too many rows for one launch");
     q.x = a->x; q.xp = a->xp; q.fp = a->fp; q.out = a->out;
     const size_t smem = stage ? (per_row * q.rb + fixed) * sizeof(T) : 0;
@@ -131,13 +140,14 @@ template <typename T> int searchsorted_impl(const spc_searchsorted_args *a, void
     if (a->n_a) REQUIRE(a->a, "a");
     if ((a->pitch_a && a->pitch_a < a->n_a) || (a->pitch_v && a->pitch_v < a->n_v) || a->pitch_out < a->n_v)
         return fail(SPC_ERR_INVALID_ARGUMENT, "%ssearchsorted: a pitch is smaller than its row (only a and v may be shared, pitch 0)");
-    if (!su_pitch_ok({a->pitch_a, a->pitch_v, a->pitch_out})) return fail(SPC_ERR_UNSUPPORTED, "%ssearchsorted: a row pitch of 2^24 elements or more");
+    if (!su_pitch_ok(a->n_rows, {a->pitch_a, a->pitch_v, a->pitch_out})) return fail(SPC_ERR_UNSUPPORTED, "%ssearchsorted: a row pitch of 2^24 elements or more");
     SuSearchP q;
     q.n_rows = a->n_rows; q.pitch_a = a->pitch_a; q.pitch_v = a->pitch_v; q.pitch_out = a->pitch_out;
     q.n_a = a->n_a; q.n_v = a->n_v; q.right = a->side_right != 0; q.p2 = floor_pow2(a->n_a);
     int stage;
     const size_t arow = (size_t)su_pad(q.p2);
-    q.rb = su_rows(a->n_rows, a->n_v, a->pitch_a ? arow : 0, a->pitch_a ? 0 : arow, sizeof(T), &stage);
+    q.rb = su_rows(a->n_rows, a->n_v, a->pitch_a ? arow : 0, a->pitch_a ? 0 : arow, sizeof(T), &stage,
+                   a->n_rows > 1 ? su_max({a->pitch_a, a->pitch_v, a->pitch_out}) : 0);
     if ((a->n_rows + q.rb - 1) / q.rb > 0x7fffffff) return fail(SPC_ERR_UNSUPPORTED, "%ssearchsorted: too many rows for one launch");
     q.a = a->a; q.v = a->v; q.out = a->out;
     const size_t smem = stage ? ((a->pitch_a ? arow : 0) * q.rb + (a->pitch_a ? 0 : arow)) * sizeof(T) : 0;
@@ -181,7 +191,7 @@ template <typename T> int interp_c_impl(const spc_interp_c_args *a, void *stream
     if (a->n_rows > 0x7fffffff) return fail(SPC_ERR_UNSUPPORTED, "%sinterp_c: more than 2^31-1 rows");
     if (a->pitch_Zh < a->nG + 1 || (a->pitch_zh && a->pitch_zh < a->nL) || a->pitch_q < a->nL - 1 || a->pitch_out < a->nG)
         return fail(SPC_ERR_INVALID_ARGUMENT, "%sinterp_c: a pitch is smaller than its row (only zh may be shared, pitch 0)");
-    if (!su_pitch_ok({a->pitch_Zh, a->pitch_zh, a->pitch_q, a->pitch_out})) return fail(SPC_ERR_UNSUPPORTED, "%sinterp_c: a row pitch of 2^24 elements or more");
+    if (!su_pitch_ok(a->n_rows, {a->pitch_Zh, a->pitch_zh, a->pitch_q, a->pitch_out})) return fail(SPC_ERR_UNSUPPORTED, "%sinterp_c: a row pitch of 2^24 elements or more");
     SuCoarseP q;
     q.n_rows = a->n_rows; q.pitch_Zh = a->pitch_Zh; q.pitch_zh = a->pitch_zh; q.pitch_q = a->pitch_q; q.pitch_out = a->pitch_out;
     q.nG = a->nG; q.nL = a->nL; q.mode = a->mode;
@@ -195,7 +205,7 @@ template <typename T> int interp_c_impl(const spc_interp_c_args *a, void *stream
     int stage;
     // 32 KiB (five workgroups per CU, what the registers allow): the layer-major walk skips whole waves above the fine grid's top, the better the more rows a wave spans (measured
     // at 35 718 rows: 5 rows 40.1 us, 7-9 rows 35.4-36.3, 12 rows 37.6: profiles/r04_k7_slab_sweep.log)
-    q.rb = su_rows(a->n_rows, a->nG, per_row, fixed, sizeof(T), &stage, 32, false);
+    q.rb = su_rows(a->n_rows, a->nG, per_row, fixed, sizeof(T), &stage, a->n_rows > 1 ? su_max({a->pitch_Zh, a->pitch_zh, a->pitch_q, a->pitch_out}) : 0, 32, false);
     const size_t smem = stage ? (per_row * q.rb + fixed) * sizeof(T) : 0;
     // numpy's pairwise recursion unrolled to the depth a layer of <= nL - 1 cells needs (cons_depth, as K4); the float twin
     // and grids of more than 1024 points keep the explicit stack

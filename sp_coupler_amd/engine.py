@@ -165,11 +165,21 @@ class OperatorPlan(_Plan):
     """a K7 operator (exner / interp / searchsorted / interp_c / rms) with its arguments frozen: ``run()`` launches and
     returns the result tensor (the caller's ``out=`` or the one allocated when the plan was made)"""
 
-    def __init__(self, engine, fn, call_args, keep, outputs, result):
+    def __init__(self, engine, fn, call_args, keep, outputs, result, refresh=()):
         super().__init__(engine, fn, call_args, keep, outputs)
         self.result = result
+        # (private contiguous copy, the caller's tensor) of every argument whose layout the kernels cannot read in place: the
+        # copy is REDONE in front of every launch, so a plan never computes from a stale snapshot of a tensor the caller
+        # has updated since (round-4 advisor).  Empty for row-contiguous arguments: run() is then one foreign call.
+        self._refresh = tuple(refresh)
 
     def run(self, stream=None):
+        if self._refresh:
+            eng = self.engine
+            st = stream if stream is not None else eng.stream
+            with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+                for snap, src in self._refresh:
+                    snap.copy_(src if src.shape == snap.shape else src.expand_as(snap))
         self.launch(stream)
         return self.result
 
@@ -514,10 +524,14 @@ class Engine:
     # -- K7: the helpers of splib/sputils.py as batched operators (sp_coupler_amd/sputils.py keeps their names) -------
     # Each operator has a ``plan_*`` form (arguments checked and the C argument block frozen ONCE, output allocated once
     # or taken from ``out=``: ``plan.run()`` is then one foreign call, no allocation) and a convenience form that builds
-    # the plan and runs it.
-    def _rows(self, name, t, n_rows=None, shared_ok=False):
+    # the plan and runs it.  Arguments are read IN PLACE when they are contiguous along their rows; anything else (a
+    # transposed view, a shared fp of interp, q / rho of different pitch) goes through a private packed copy that run()
+    # refreshes from the caller's tensor before every launch -- a plan never serves a stale snapshot.
+    def _rows(self, name, t, n_rows=None, shared_ok=False, refresh=None):
         """(tensor, data_ptr, pitch, n): a [n_rows x n] matrix contiguous along n (pitch = row stride), or -- where the
-        operator allows it -- ONE [n] row shared by all rows (pitch 0)"""
+        operator allows it -- ONE [n] row shared by all rows (pitch 0).  A tensor the kernels cannot read in place is
+        copied; the (copy, original) pair is appended to ``refresh`` so that a plan can redo the copy before every run."""
+        orig = t
         if not isinstance(t, torch.Tensor):
             raise TypeError("%s must be a torch.Tensor, got %s" % (name, type(t).__name__))
         if t.device != self.device or t.dtype != self.dtype:
@@ -526,6 +540,8 @@ class Engine:
             if not shared_ok and n_rows not in (None, 1):
                 raise ValueError("%s must have %d rows, got one" % (name, n_rows))
             t = t.contiguous()
+            if refresh is not None and t is not orig:
+                refresh.append((t, orig))
             return t, t.data_ptr(), (0 if shared_ok and n_rows not in (None, 1) else max(1, t.shape[0])), int(t.shape[0])
         if t.dim() != 2:
             raise ValueError("%s must be [n] or [n_rows x n], got %s" % (name, tuple(t.shape)))
@@ -533,6 +549,8 @@ class Engine:
             raise ValueError("%s must have %d rows, got %d" % (name, n_rows, t.shape[0]))
         if t.shape[1] > 1 and t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
             t = t.contiguous()
+            if refresh is not None:
+                refresh.append((t, orig))
         return t, t.data_ptr(), (int(t.stride(0)) if t.shape[0] > 1 else max(1, int(t.shape[1]))), int(t.shape[1])
 
     def _out(self, out, n_rows, n, dtype=None):
@@ -561,13 +579,17 @@ class Engine:
         """sputils.exner / iexner (splib/sputils.py:28-34), elementwise on a device tensor of any shape"""
         if p.device != self.device or p.dtype != self.dtype:
             raise ValueError("p must be %s on %s" % (self.dtype, self.device))
-        p = p.contiguous()
+        refresh = []
+        if not p.is_contiguous():
+            src, p = p, p.contiguous()
+            refresh.append((p, src))
         if out is None:
             out = torch.empty_like(p)
         elif not isinstance(out, torch.Tensor) or out.device != self.device or out.dtype != self.dtype or out.shape != p.shape or not out.is_contiguous():
             raise ValueError("out must be a contiguous %s tensor of shape %s on %s" % (self.dtype, tuple(p.shape), self.device))
         fn = getattr(self.lib, "spc_exner_" + _DTYPES[self.dtype])
-        return OperatorPlan(self, fn, (p.numel(), p.data_ptr(), out.data_ptr(), 1 if inverse else 0), [p, out], {"out": out}, result=out)
+        return OperatorPlan(self, fn, (p.numel(), p.data_ptr(), out.data_ptr(), 1 if inverse else 0), [p, out], {"out": out}, result=out,
+                            refresh=refresh)
 
     def exner(self, p, inverse=False, stream=None, out=None):
         return self.plan_exner(p, inverse, out=out).run(stream)
@@ -579,16 +601,21 @@ class Engine:
         argument is 1-D)."""
         one = fp.dim() == 1 and xp.dim() == 1 and x.dim() == 1
         n_rows = max(int(t.shape[0]) if t.dim() == 2 else 1 for t in (x, xp, fp))
-        fp2 = fp.unsqueeze(0).expand(n_rows, -1).contiguous() if (fp.dim() == 1 and n_rows > 1) else fp
-        fp2, p_fp, pitch_fp, n_xp = self._rows("fp", fp2, n_rows)
-        xp2, p_xp, pitch_xp, n_xp2 = self._rows("xp", xp, n_rows, shared_ok=True)
-        x2, p_x, pitch_x, n_x = self._rows("x", x, n_rows, shared_ok=True)
+        refresh = []
+        if fp.dim() == 1 and n_rows > 1:          # the ABI has one fp row per result row: a shared fp is spread (and re-spread per run)
+            fp2 = fp.unsqueeze(0).expand(n_rows, -1).contiguous()
+            refresh.append((fp2, fp.unsqueeze(0)))
+        else:
+            fp2 = fp
+        fp2, p_fp, pitch_fp, n_xp = self._rows("fp", fp2, n_rows, refresh=refresh)
+        xp2, p_xp, pitch_xp, n_xp2 = self._rows("xp", xp, n_rows, shared_ok=True, refresh=refresh)
+        x2, p_x, pitch_x, n_x = self._rows("x", x, n_rows, shared_ok=True, refresh=refresh)
         if n_xp2 != n_xp:
             raise ValueError("fp and xp are not of the same length")          # numpy.interp's message
         out, pitch_out = self._out(out, n_rows, n_x)
         a = _abi.InterpArgs(n_rows, n_x, n_xp, pitch_x, pitch_xp, pitch_fp, pitch_out, p_x, p_xp, p_fp, out.data_ptr())
         fn = getattr(self.lib, "spc_interp_" + _DTYPES[self.dtype])
-        return OperatorPlan(self, fn, (ctypes.byref(a),), [fp2, xp2, x2, out, a], {"out": out}, result=out[0] if one else out)
+        return OperatorPlan(self, fn, (ctypes.byref(a),), [fp2, xp2, x2, out, a], {"out": out}, result=out[0] if one else out, refresh=refresh)
 
     def interp(self, x, xp, fp, stream=None, out=None):
         return self.plan_interp(x, xp, fp, out=out).run(stream)
@@ -600,12 +627,13 @@ class Engine:
             raise ValueError("side must be 'left' or 'right'")
         one = a.dim() == 1 and v.dim() == 1
         n_rows = max(int(t.shape[0]) if t.dim() == 2 else 1 for t in (a, v))
-        a2, p_a, pitch_a, n_a = self._rows("a", a, n_rows, shared_ok=True)
-        v2, p_v, pitch_v, n_v = self._rows("v", v, n_rows, shared_ok=True)
+        refresh = []
+        a2, p_a, pitch_a, n_a = self._rows("a", a, n_rows, shared_ok=True, refresh=refresh)
+        v2, p_v, pitch_v, n_v = self._rows("v", v, n_rows, shared_ok=True, refresh=refresh)
         out, pitch_out = self._out(out, n_rows, n_v, dtype=torch.int64)
         args = _abi.SearchsortedArgs(n_rows, n_a, n_v, pitch_a, pitch_v, pitch_out, p_a, p_v, out.data_ptr(), 1 if side == "right" else 0, 0)
         fn = getattr(self.lib, "spc_searchsorted_" + _DTYPES[self.dtype])
-        return OperatorPlan(self, fn, (ctypes.byref(args),), [a2, v2, out, args], {"out": out}, result=out[0] if one else out)
+        return OperatorPlan(self, fn, (ctypes.byref(args),), [a2, v2, out, args], {"out": out}, result=out[0] if one else out, refresh=refresh)
 
     def searchsorted(self, a, v, side="left", stream=None, out=None):
         return self.plan_searchsorted(a, v, side, out=out).run(stream)
@@ -620,18 +648,25 @@ class Engine:
             raise ValueError("mode must be one of %s" % sorted(modes))
         one = Zh.dim() == 1 and q.dim() == 1
         n_rows = max(int(t.shape[0]) if t.dim() == 2 else 1 for t in (Zh, q))
-        Zh2, p_Zh, pitch_Zh, nGh = self._rows("Zh", Zh, n_rows)
-        zh2, p_zh, pitch_zh, nL = self._rows("zh", zh, n_rows, shared_ok=True)
-        q2, p_q, pitch_q, nq = self._rows("q", q, n_rows)
+        refresh = []
+        Zh2, p_Zh, pitch_Zh, nGh = self._rows("Zh", Zh, n_rows, refresh=refresh)
+        zh2, p_zh, pitch_zh, nL = self._rows("zh", zh, n_rows, shared_ok=True, refresh=refresh)
+        q2, p_q, pitch_q, nq = self._rows("q", q, n_rows, refresh=refresh)
         if nq < nL - 1:
             raise ValueError("q has %d values, the %d grid points of zh bound %d cells" % (nq, nL, nL - 1))
         p_rho, rho2 = None, None
         if rho is not None and mode != "interp_rho":
-            rho2, p_rho, pitch_rho, nr = self._rows("rho", rho, n_rows)
+            rho2, p_rho, pitch_rho, nr = self._rows("rho", rho, n_rows, refresh=refresh)
             if nr != nq:
                 raise ValueError("rho and q must have the same shape")
-            if n_rows > 1 and pitch_rho != pitch_q:            # the ABI has ONE pitch for q and rho
-                rho2, q2 = rho2.contiguous(), q2.contiguous()
+            if n_rows > 1 and pitch_rho != pitch_q:            # the ABI has ONE pitch for q and rho: both packed (and re-packed per run)
+                refresh[:] = [pr for pr in refresh if pr[0] is not rho2 and pr[0] is not q2]
+                rho2, q2 = rho.contiguous(), q.contiguous()
+                if rho2 is rho:
+                    rho2 = rho.clone()
+                if q2 is q:
+                    q2 = q.clone()
+                refresh += [(rho2, rho), (q2, q)]
                 p_rho, p_q, pitch_q = rho2.data_ptr(), q2.data_ptr(), max(1, nq)
         elif mode == "interp_c":
             raise ValueError("interp_c needs the weights rho")
@@ -639,7 +674,7 @@ class Engine:
         out, pitch_out = self._out(out, n_rows, max(nG, 0))
         a = _abi.InterpCArgs(n_rows, nG, nL, pitch_Zh, pitch_zh, pitch_q, pitch_out, p_Zh, p_zh, p_q, p_rho, out.data_ptr(), modes[mode], 0)
         fn = getattr(self.lib, "spc_interp_c_" + _DTYPES[self.dtype])
-        return OperatorPlan(self, fn, (ctypes.byref(a),), [Zh2, zh2, q2, rho2, out, a], {"out": out}, result=out[0] if one else out)
+        return OperatorPlan(self, fn, (ctypes.byref(a),), [Zh2, zh2, q2, rho2, out, a], {"out": out}, result=out[0] if one else out, refresh=refresh)
 
     def interp_c(self, Zh, zh, q, rho=None, mode="interp_c", stream=None, out=None):
         return self.plan_interp_c(Zh, zh, q, rho, mode, out=out).run(stream)
@@ -648,7 +683,8 @@ class Engine:
     def plan_rms(self, a, out=None):
         """sputils.rms (splib/sputils.py:23-24) of every row of a [n_rows x n] tensor (of the one row of a 1-D tensor)"""
         one = a.dim() == 1
-        a2, p_a, pitch, n = self._rows("a", a)
+        refresh = []
+        a2, p_a, pitch, n = self._rows("a", a, refresh=refresh)
         n_rows = 1 if one else int(a2.shape[0])
         if out is None:
             out = self.empty(n_rows)
@@ -656,7 +692,8 @@ class Engine:
                 or not out.is_contiguous():
             raise ValueError("out must be a contiguous %s vector of %d on %s" % (self.dtype, n_rows, self.device))
         fn = getattr(self.lib, "spc_rms_" + _DTYPES[self.dtype])
-        return OperatorPlan(self, fn, (n_rows, n, max(pitch, n), p_a, out.data_ptr()), [a2, out], {"out": out}, result=out[0] if one else out)
+        return OperatorPlan(self, fn, (n_rows, n, max(pitch, n), p_a, out.data_ptr()), [a2, out], {"out": out}, result=out[0] if one else out,
+                            refresh=refresh)
 
     def rms(self, a, stream=None, out=None):
         return self.plan_rms(a, out=out).run(stream)

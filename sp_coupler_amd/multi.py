@@ -157,38 +157,84 @@ class MultiDeviceEngine:
         bp = self.plan_backward(gcm, zf, prof, factor_gcm, dt, Zf=None, want_start_index=False, cols_per_block=cols_per_block)
         return fp, bp
 
-    # -- convenience / slow paths: the whole batch on the primary device ----------------------------------------------
-    def whole(self, x, device):
-        """x (tensor / Sharded / dict of them) as whole tensors on ``device``; the engines' streams are drained first"""
-        if isinstance(x, Sharded):
-            self.synchronize()
-            return x.gather(device)
-        if isinstance(x, dict):
-            return {k: self.whole(v, device) for k, v in x.items()}
-        return x
+    # -- convenience forms and slow paths: per device, on that device's rows (round 5; rounds 3-4 gathered the whole batch
+    #    onto the primary device first -- 14 GB onto one card at config 4) -----------------------------------------------
+    @staticmethod
+    def _example(*xs):
+        """the first row-sharded argument (a Sharded with bounds), else None: plain tensors run on the primary engine"""
+        for x in xs:
+            if isinstance(x, dict):
+                x = MultiDeviceEngine._example(*x.values())
+            if isinstance(x, Sharded) and x.bounds is not None:
+                return x
+        return None
+
+    def _each(self, name, ex, args, kw):
+        """``engine.<name>(*args, **kw)`` on every device that holds rows of ``ex``, with every Sharded argument replaced by
+        that device's block; returns the per-device results (None for devices without rows)"""
+        res = []
+        for d, e in enumerate(self.engines):
+            if ex.bounds[d + 1] <= ex.bounds[d]:
+                res.append(None)
+                continue
+            a = [_parts_of(x, d) if isinstance(x, dict) else _part(x, d) for x in args]
+            k = {key: (_parts_of(v, d) if isinstance(v, dict) else _part(v, d)) for key, v in kw.items()}
+            res.append(getattr(e, name)(*a, **k))
+        return res
+
+    @staticmethod
+    def _join(results, bounds):
+        """per-device results (tensors, tuples or dicts of tensors) -> the same shape of Sharded arrays"""
+        ref = next(r for r in results if r is not None)
+        pick = lambda r, get: get(r) if r is not None else get(ref)[:0]                       # noqa: E731
+        if isinstance(ref, dict):
+            return {k: Sharded([pick(r, lambda x, k=k: x[k]) for r in results], bounds) for k in ref}
+        if isinstance(ref, (tuple, list)):
+            return tuple(Sharded([pick(r, lambda x, i=i: x[i]) for r in results], bounds) for i in range(len(ref)))
+        return Sharded([pick(r, lambda x: x) for r in results], bounds)
+
+    def _run(self, name, *args, **kw):
+        ex = self._example(*args, *kw.values())
+        if ex is None:
+            return getattr(self.primary, name)(*args, **kw)
+        return self._join(self._each(name, ex, args, kw), ex.bounds)
 
     def forward(self, gcm, zf, prof, factor, dt, **kw):
-        w = lambda x: self.whole(x, self.primary.device)       # noqa: E731
-        if "zh" in kw:
-            kw["zh"] = w(kw["zh"])
-        return self.primary.forward(w(gcm), w(zf), w(prof), factor, dt, **kw)
+        return self._run("forward", gcm, zf, prof, factor, dt, **kw)
 
     def backward(self, gcm, zf, prof, factor, dt, **kw):
-        w = lambda x: self.whole(x, self.primary.device)       # noqa: E731
-        return self.primary.backward(w(gcm), w(zf), w(prof), factor, dt, **{k: w(v) for k, v in kw.items()})
+        return self._run("backward", gcm, zf, prof, factor, dt, **kw)
 
     def diagnostics(self, gcm, zf=None, prof=None, **kw):
-        w = lambda x: self.whole(x, self.primary.device)       # noqa: E731
-        return self.primary.diagnostics(w(gcm), w(zf), w(prof), **kw)
+        return self._run("diagnostics", gcm, zf, prof, **kw)
 
     def cloud_indices(self, zh, Zh, **kw):
-        return self.primary.cloud_indices(self.whole(zh, self.primary.device), self.whole(Zh, self.primary.device), **kw)
+        return self._run("cloud_indices", zh, Zh, **kw)
 
     def surface_fluxes(self, *a, **kw):
-        return self.primary.surface_fluxes(*a, **kw)
+        return self._run("surface_fluxes", *a, **kw)
 
     def variability_nudge(self, *a, **kw):
-        return self.primary.variability_nudge(*a, **kw)
+        """K6 on every device's LES (spcpl.py:377-382 nudges one LES at a time; columns are independent): Sharded fields in,
+        Sharded results out, ``qt`` / ``thl`` updated in place block by block"""
+        return self._run("variability_nudge", *a, **kw)
+
+    # the helpers of splib/sputils.py (K7) on row-sharded arguments: each device runs the operator on its rows; an argument
+    # shared by all rows (a 1-D grid) is a replicated Sharded (``to_devices(host)``) or a plain tensor on the primary device
+    def exner(self, p, inverse=False, **kw):
+        return self._run("exner", p, inverse=inverse, **kw)
+
+    def interp(self, x, xp, fp, **kw):
+        return self._run("interp", x, xp, fp, **kw)
+
+    def searchsorted(self, a, v, side="left", **kw):
+        return self._run("searchsorted", a, v, side=side, **kw)
+
+    def interp_c(self, Zh, zh, q, rho=None, mode="interp_c", **kw):
+        return self._run("interp_c", Zh, zh, q, rho, mode=mode, **kw)
+
+    def rms(self, a, **kw):
+        return self._run("rms", a, **kw)
 
     def on_stream(self):
         """the slow paths run on the primary engine: its stream context (Engine.on_stream)"""

@@ -112,7 +112,7 @@ def _to_host(t):
     """device tensor (or a transfer.Sharded array of a multi-device engine) -> NumPy array.  Callers on the slow paths run
     under ``engine.on_stream()``, so the copy is ordered behind the engine's launches."""
     if isinstance(t, transfer.Sharded):
-        t = t.gather()
+        return t.to_host()          # block by block, concatenated on the host: no device holds the whole batch
     return t.cpu().numpy()
 
 
@@ -676,8 +676,8 @@ def convert_profiles(les, write=True):
         eng = batch.engine
         nL = batch.zf.shape[-1]
         with eng.on_stream():
-            z = torch.zeros(batch.n, nL, device=eng.device, dtype=eng.dtype)
-            dummy = {"U": z, "V": z, "THL": z, "QT": z, "QL": z, "PS": torch.zeros(batch.n, device=eng.device, dtype=eng.dtype)}
+            z = eng.to_devices(numpy.zeros((batch.n, nL)), rows=batch.n)        # row blocks per device when the batch is sharded
+            dummy = {"U": z, "V": z, "THL": z, "QT": z, "QL": z, "PS": eng.to_devices(numpy.zeros(batch.n), rows=batch.n)}
         _inputs_ready(batch)
         with eng.on_stream():
             res = eng.forward(batch.gcm, batch.zf, dummy, 0.0, 1.0, want_profiles=True, want_heights=True)
@@ -811,11 +811,12 @@ def convert_surface_fluxes(les):
         eng = get_engine()
         Ph, T = numpy.atleast_2d(_num(les["Ph"])), numpy.atleast_2d(_num(les["T"]))   # KeyError if missing, spcpl.py:146
         one = numpy.ndim(_num(les["T"])) == 1
-        dev = lambda a: torch.from_numpy(numpy.ascontiguousarray(numpy.atleast_1d(_num(a)))).to(eng.device, eng.dtype)  # noqa: E731
+        n = Ph.shape[0]
+        dev = lambda a: eng.to_devices(numpy.ascontiguousarray(numpy.atleast_1d(_num(a)), dtype=numpy.float64), rows=n)  # noqa: E731
         with eng.on_stream():
             wthl, wqt = eng.surface_fluxes(dev(Ph[:, -1]), dev(T[:, -1]), dev(les["QLflux"]), dev(les["QIflux"]),
                                            dev(les["SHflux"]), dev(les["TSflux"]))
-            wthl, wqt = wthl.cpu().numpy(), wqt.cpu().numpy()
+            wthl, wqt = _to_host(wthl), _to_host(wqt)
         sel = (lambda a: a[0]) if one else (lambda a: a)
         return les.get("Z0M"), les.get("Z0H"), _wrap("wthl", sel(wthl)), _wrap("wqt", sel(wqt))
     batch = _batch_of(les)
@@ -1162,45 +1163,70 @@ VN_MAX_COLS = 32767          # columns per launch of spc_variability_nudge_f64 (
 
 
 def _vnudge_chunk(eng, n, itot, jtot, ktot, constantT):
-    """columns per launch: the kernel's limit, and what fits the device -- fields (qt, qsat; thl, ql with constantT), the
-    transposed-plane workspace, R and the profiles, within 80 % of the memory that is free now.  The reference loops over any
-    number of LES (splib/spcpl.py:377-382); columns are independent, so chunks give the bits of one launch."""
+    """columns per launch on ONE engine: the kernel's limit, and what fits its device -- fields (qt, qsat; thl, ql with
+    constantT), the transposed-plane workspace, R and the profiles, within 80 % of the memory that is available now: what the
+    driver reports free PLUS what torch's caching allocator holds without using it (after a few coupled steps most of the
+    free memory sits there).  The reference loops over any number of LES (splib/spcpl.py:377-382); columns are independent, so
+    chunks give the bits of one launch."""
     chunk = min(int(VN_MAX_COLS), n)
-    dev = getattr(getattr(eng, "primary", eng), "device", None)
+    dev = getattr(eng, "device", None)
     if dev is not None and dev.type == "cuda":
         lib = getattr(eng, "lib", None)
         per_col = (4 if constantT else 2) * itot * jtot * ktot * 8 + itot * jtot * 8 + 8 * ktot * 8
         if lib is not None:
             per_col += max(0, int(lib.spc_vnudge_workspace_bytes(1, itot, jtot, ktot)))
         free, _ = torch.cuda.mem_get_info(dev)
+        free += max(0, torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev))
         chunk = max(1, min(chunk, int(0.8 * free) // max(per_col, 1)))
+        if chunk < n:
+            log.info("sp_coupler_amd: variability nudge of %d LES on %s in launches of %d (%.1f GiB available, %.2f GiB per LES)",
+                     n, dev, chunk, free / 2.0 ** 30, per_col / 2.0 ** 30)
     return chunk
 
 
 def _vnudge_launch(F, Rs, constantT):
     """stacked host arrays -> as few launches of K6 as the kernel's column limit and the device memory allow -> host results;
-    ``F``: dict of [n x ...] arrays"""
+    ``F``: dict of [n x ...] arrays.  With several engines (multi.MultiDeviceEngine) the LES are dealt out in contiguous row
+    blocks, one per device (sharding.shard_bounds, as every other array of the batch), and each device nudges ITS LES: the 3-D
+    fields -- the largest objects in the system -- never meet on one card.  Chunks are issued in rounds, one chunk per device
+    and round: uploads and launches of a round go out device by device (asynchronous), then the results come back."""
+    from .sharding import shard_bounds
     eng = get_engine()
-    dev, dt = eng.device, eng.dtype
-    up = lambda a: torch.from_numpy(numpy.ascontiguousarray(a)).to(dev, dt)      # noqa: E731
+    engines = list(getattr(eng, "engines", None) or [eng])
     n, itot, jtot, ktot = F["qt"].shape
-    chunk = _vnudge_chunk(eng, n, itot, jtot, ktot, constantT)
-    hosts, qts, thls = [], [], []
-    for lo in range(0, n, chunk):
-        hi = min(n, lo + chunk)
-        with eng.on_stream():
-            T = {k: up(v[lo:hi]) for k, v in F.items() if v is not None}
-            res = eng.variability_nudge(T["qt"], T["qsat"], up(Rs[lo:hi]), T["ql_av"], T["qt_av"], T["ql_ref"], presf=T["presf"],
-                                        thl=T.get("thl"), ql=T.get("ql"), constantT=constantT)
-            hosts.append({k: v.cpu().numpy() for k, v in res.items()})
-            qts.append(T["qt"].cpu().numpy())
-            if constantT:
-                thls.append(T["thl"].cpu().numpy())
-            del T, res
-    if len(hosts) == 1:
-        return hosts[0], qts[0], (thls[0] if constantT else None)
-    host = {k: numpy.concatenate([h[k] for h in hosts], axis=0) for k in hosts[0]}
-    return host, numpy.concatenate(qts, axis=0), (numpy.concatenate(thls, axis=0) if constantT else None)
+    k = max(1, min(len(engines), n))
+    bounds = shard_bounds(n, k)
+    queues = []                                                # per device: its chunks (lo, hi) in row order
+    for d in range(k):
+        lo, hi = bounds[d], bounds[d + 1]
+        chunk = _vnudge_chunk(engines[d], hi - lo, itot, jtot, ktot, constantT) if hi > lo else 1
+        queues.append([(c, min(hi, c + chunk)) for c in range(lo, hi, chunk)])
+    host = None
+    qt_out = numpy.empty_like(F["qt"])
+    thl_out = numpy.empty_like(F["thl"]) if constantT else None
+    for rnd in range(max(len(q) for q in queues)):
+        live = []
+        for d, q in enumerate(queues):
+            if rnd >= len(q):
+                continue
+            e, (lo, hi) = engines[d], q[rnd]
+            up = lambda a, e=e: torch.from_numpy(numpy.ascontiguousarray(a)).to(e.device, e.dtype)      # noqa: E731
+            with e.on_stream():
+                T = {key: up(v[lo:hi]) for key, v in F.items() if v is not None}
+                res = e.variability_nudge(T["qt"], T["qsat"], up(Rs[lo:hi]), T["ql_av"], T["qt_av"], T["ql_ref"], presf=T["presf"],
+                                          thl=T.get("thl"), ql=T.get("ql"), constantT=constantT)
+            live.append((e, lo, hi, T, res))
+        for e, lo, hi, T, res in live:
+            with e.on_stream():
+                if host is None:
+                    host = {key: numpy.empty((n,) + tuple(v.shape[1:]), dtype=torch.empty(0, dtype=v.dtype).numpy().dtype) for key, v in res.items()}
+                for key, v in res.items():
+                    host[key][lo:hi] = v.cpu().numpy()
+                qt_out[lo:hi] = T["qt"].cpu().numpy()
+                if constantT:
+                    thl_out[lo:hi] = T["thl"].cpu().numpy()
+        del live
+    return host, qt_out, thl_out
 
 
 def _vnudge_finish(host, rows, dtv, write):
@@ -1308,8 +1334,8 @@ def output_column_conversion(profile):
         for src, dst in (("T", "T"), ("SH", "SH"), ("QL", "QL"), ("QI", "QI"), ("Pf", "Pfull"), ("Zgfull", "Zgfull"),
                          ("Zghalf", "Zghalf")):
             a = numpy.atleast_2d(_num(profile[src]))
-            g[dst] = torch.from_numpy(numpy.ascontiguousarray(a)).to(eng.device, eng.dtype)
-        d = {k: v.cpu().numpy() for k, v in eng.diagnostics(g).items()}
+            g[dst] = eng.to_devices(numpy.ascontiguousarray(a, dtype=numpy.float64), rows=a.shape[0])
+        d = {k: _to_host(v) for k, v in eng.diagnostics(g).items()}
     sel = (lambda a: a[0]) if one else (lambda a: a)
     Ph = numpy.atleast_2d(_num(profile["Ph"]))
     profile["Tv"] = sel(d["Tv"])

@@ -16,6 +16,8 @@ helper on its own.  Host-only helpers of the reference's module that are not ari
 import numpy
 import torch
 
+from .transfer import Sharded
+
 # Physical constants, splib/sputils.py:14-20 (plain numbers: SI-coherent units, factor 1)
 pref0 = 1e5       # Pa reference pressure
 rd = 287.04       # J/kg/K gas constant for dry air
@@ -28,8 +30,7 @@ mair = 28.967     # g/mol molar mass of air
 
 def _engine():
     from . import spcpl
-    eng = spcpl.get_engine()
-    return getattr(eng, "primary", eng)          # multi.MultiDeviceEngine: helpers run on its first device
+    return spcpl.get_engine()
 
 
 def _num(a, unit=None):
@@ -54,23 +55,48 @@ def _with_unit(value, unit):
 
 
 class _Io:
-    """moves the arguments of one call to the engine's device and the result back to where they came from"""
+    """moves the arguments of one call to the engine's device(s) and the result back to where they came from.  With a
+    multi.MultiDeviceEngine a batch of rows (2-D arguments from the host, enough rows) is dealt out in row blocks, one per
+    device, each device runs the operator on ITS rows and the result is concatenated on the host (round 5; rounds 3-4 ran
+    every helper on the first device); 1-D arguments shared by all rows are replicated."""
 
     def __init__(self):
-        self.eng = _engine()
+        eng = _engine()
+        self.multi = eng if hasattr(eng, "engines") else None
+        self.eng = eng
         self.on_device = False
+        self.sharded = False
 
-    def dev(self, a, dtype=None, unit=None):
+    def _host(self, a, unit=None):
         a = _num(a, unit)
         if isinstance(a, torch.Tensor):
-            self.on_device = self.on_device or a.device.type == "cuda"
-            return a.to(self.eng.device, dtype or self.eng.dtype)
+            return a
         a = numpy.asarray(a, dtype=numpy.float64)
         if a.ndim:                                  # (ascontiguousarray would turn a 0-d scalar into a vector)
             a = numpy.ascontiguousarray(a)          # negative strides ([::-1] views) included
-        return torch.from_numpy(a.copy() if not a.flags.writeable else a).to(self.eng.device, dtype or self.eng.dtype)
+        return a.copy() if not a.flags.writeable else a
+
+    def devs(self, *args, shard=True):
+        """every argument of one call -- bare values or (value, unit-to-convert-to) pairs; None passes through -- on the
+        device(s): ONE decision for the whole call, so that row-sharded and replicated arguments share a partition"""
+        pairs = [(a if isinstance(a, tuple) else (a, None)) for a in args]
+        vals = [None if v is None else self._host(v, u) for v, u in pairs]
+        tensors = [v for v in vals if isinstance(v, torch.Tensor)]
+        self.on_device = any(t.device.type == "cuda" for t in tensors)
+        rows = max([v.shape[0] for v in vals if isinstance(v, numpy.ndarray) and v.ndim == 2] or [0])
+        if shard and self.multi is not None and not tensors and rows and self.multi.devices_for(rows) > 1:
+            self.sharded = True
+            return [None if v is None else self.multi.to_devices(v, rows=rows if v.ndim == 2 else None, n_cols=rows) for v in vals]
+        self.eng = primary = getattr(self.eng, "primary", self.eng)
+        return [None if v is None else (v if isinstance(v, torch.Tensor) else torch.from_numpy(v)).to(primary.device, primary.dtype)
+                for v in vals]
+
+    def dev(self, a, dtype=None, unit=None):
+        return self.devs((a, unit))[0]
 
     def back(self, t, scalar=False):
+        if isinstance(t, Sharded):
+            return t.to_host()
         if self.on_device:
             return t
         out = t.cpu().numpy()
@@ -96,12 +122,25 @@ def rms(a, axis=None):
     the reference (numpy.mean over every axis).  ``axis=-1`` (beyond the reference): the rms of every row of a 2-D array."""
     io = _Io()
     unit = _unit(a)
-    ad = io.dev(a)
     if axis is None:
-        ad = ad.reshape(-1)                         # C order: numpy reduces a contiguous array as one flat run
-    elif axis not in (-1, 1) or ad.dim() != 2:
+        a = _num(a)
+        a = a.reshape(-1) if isinstance(a, torch.Tensor) else numpy.asarray(a, dtype=numpy.float64).reshape(-1)   # C order: ONE flat run
+    ad = io.dev(a)
+    if axis is not None and (axis not in (-1, 1) or ad.dim() != 2):
         raise ValueError("rms: axis must be None (whole array, as the reference) or -1 on a 2-D array (per row)")
     return _with_unit(io.back(io.eng.rms(ad), scalar=ad.dim() == 1), unit)
+
+
+def _outside(r, xd, xpd, left, right):
+    """numpy.interp's ``left`` / ``right``: two selects behind the kernel (NaN abscissae keep the kernel's NaN)"""
+    def fix(r_, x_, xp_):
+        lo, hi = xp_[..., :1], xp_[..., -1:]
+        if left is not None:
+            r_ = torch.where(x_ < lo, torch.as_tensor(float(_num(left)), dtype=r_.dtype, device=r_.device), r_)
+        if right is not None:
+            r_ = torch.where(x_ > hi, torch.as_tensor(float(_num(right)), dtype=r_.dtype, device=r_.device), r_)
+        return r_
+    return r.map(fix, xd, xpd) if isinstance(r, Sharded) else fix(r, xd, xpd)
 
 
 def interp(x, xp, fp, **kwargs):
@@ -114,18 +153,14 @@ def interp(x, xp, fp, **kwargs):
         raise NotImplementedError("sputils.interp on the GPU: numpy.interp's period / %s not supported" % sorted(kwargs))
     io = _Io()
     ux, ufp = _unit(x), _unit(fp)
-    xd, xpd, fpd = io.dev(x), io.dev(xp, unit=ux), io.dev(fp)
+    xd, xpd, fpd = io.devs(x, (xp, ux), fp)
     scalar = xd.dim() == 0
     if scalar:
         xd = xd.reshape(1)
     r = io.eng.interp(xd, xpd, fpd)
-    if left is not None or right is not None:        # two selects behind the kernel (NaN abscissae keep the kernel's NaN)
+    if left is not None or right is not None:
         with io.eng.on_stream():
-            lo, hi = xpd[..., :1], xpd[..., -1:]
-            if left is not None:
-                r = torch.where(xd < lo, torch.as_tensor(float(_num(left)), dtype=r.dtype, device=r.device), r)
-            if right is not None:
-                r = torch.where(xd > hi, torch.as_tensor(float(_num(right)), dtype=r.dtype, device=r.device), r)
+            r = _outside(r, xd, xpd, left, right)
     return _with_unit(io.back(r[..., 0] if scalar else r, scalar=scalar and r.dim() == 1), ufp)
 
 
@@ -135,7 +170,7 @@ def searchsorted(a, v, **kwargs):
     if kwargs:
         raise NotImplementedError("sputils.searchsorted on the GPU: numpy.searchsorted's %s not supported" % sorted(kwargs))
     io = _Io()
-    ad, vd = io.dev(a), io.dev(v, unit=_unit(a))                      # v.value_in(a.unit), splib/sputils.py:91
+    ad, vd = io.devs(a, (v, _unit(a)))                                # v.value_in(a.unit), splib/sputils.py:91
     scalar = vd.dim() == 0
     if scalar:
         vd = vd.reshape(1)
@@ -148,13 +183,11 @@ def integral(a, b, z, q, w=None):
     splib/sputils.py:94-161.  Returns None when an end point lies outside z, as the reference does (scalar call); with
     arrays a, b of n_rows end points (and 2-D z / q / w or shared 1-D z) the rows outside give NaN."""
     io = _Io()
-    ad, bd = io.dev(a), io.dev(b)
+    ad, bd, zd, qd, wd = io.devs(a, b, z, q, w, shard=False)            # end points per row: assembled with torch ops on ONE device
     scalar = ad.dim() == 0 and bd.dim() == 0
     if not scalar:                                                       # one end point given for all rows: broadcast
         ad, bd = torch.broadcast_tensors(ad.reshape(-1) if ad.dim() else ad.reshape(1), bd.reshape(-1) if bd.dim() else bd.reshape(1))
     Zh = torch.stack([bd.reshape(-1), ad.reshape(-1)], dim=1)            # layer k = [Zh[k+1], Zh[k]] = [a, b]
-    zd, qd = io.dev(z), io.dev(q)
-    wd = io.dev(w) if w is not None else None
     if scalar:
         if zd.shape[-1] != qd.shape[-1] + 1:
             print("len(z) should be len(q) + 1. len(z)=%d, len(q) = %d", (zd.shape[-1], qd.shape[-1]))      # sputils.py:111-112
@@ -177,13 +210,15 @@ def interp_c(Zh, zh, q, rho):
     """conservative interpolation from fine to coarse levels (splib/sputils.py:173-189): Q[i] = rho-weighted mean of q over
     [Zh[i+1], Zh[i]] where Zh[i] < zh[-1], else 0.  One column (1-D) or [n_cols x ...] batches (zh may stay 1-D)."""
     io = _Io()
-    return io.back(io.eng.interp_c(io.dev(Zh), io.dev(zh), io.dev(q), io.dev(rho), mode="interp_c"))
+    Zd, zd, qd, rd_ = io.devs(Zh, zh, q, rho)
+    return io.back(io.eng.interp_c(Zd, zd, qd, rd_, mode="interp_c"))
 
 
 def interp_rho(Zh, zh, rho):
     """a density on the coarser grid (splib/sputils.py:191-197): integral(Zh[i+1], Zh[i], zh, rho) / (Zh[i] - Zh[i+1])"""
     io = _Io()
-    return io.back(io.eng.interp_c(io.dev(Zh), io.dev(zh), io.dev(rho), None, mode="interp_rho"))
+    Zd, zd, rd_ = io.devs(Zh, zh, rho)
+    return io.back(io.eng.interp_c(Zd, zd, rd_, None, mode="interp_rho"))
 
 
 def find_closest_points(points, target):

@@ -40,7 +40,9 @@ class Arena:
             self.begin[name], self.end[name] = o, o + nb
         self.done = None        # event of the last download (created on first use)
         self.side, self.pushed, self.landed, self.pending, self.deferred, self.deferred_what = None, False, {}, {}, None, "h2d"
-        self.sent, self.sent_ev = {}, {}     # name -> event recorded behind the last upload of that array (writable())
+        # name -> {stream handle: event recorded behind the last upload of that array ON THAT STREAM} (writable()); an event
+        # object is shared by the names one copy carried, counted in _ev_refs and re-recorded only when no name refers to it
+        self.sent, self._ev_refs, self._ev_free = {}, {}, []
 
     def _cur(self):
         """the compute stream every copy of this buffer is ordered against"""
@@ -64,25 +66,39 @@ class Arena:
                 dst.copy_(src, non_blocking=True)
 
     def _mark_sent(self, names, stream):
-        """one event behind the copy that carried ``names`` up: the host may refill them once it has fired"""
+        """one event behind the copy that carried ``names`` up: the host may refill them once it has fired.  A later copy of
+        the same array on the SAME stream supersedes the earlier one (stream order); copies on different streams (upload()
+        / fence() on the compute stream, push() on the copy stream) are both kept, and writable() waits for all of them.
+        (Round-4 advisor: the event used to be keyed by the first name of the copy and shared by reference -- a later copy
+        starting with the same name re-recorded the object other names were still waiting on, on another stream.)"""
         if not names:
             return
-        ev = self.sent_ev.get(names[0])
-        if ev is None:
-            ev = self.sent_ev[names[0]] = torch.cuda.Event()
+        ev = self._ev_free.pop() if self._ev_free else torch.cuda.Event()
         ev.record(stream)
+        key = stream.cuda_stream
+        self._ev_refs[ev] = len(names)
         for nm in names:
-            self.sent[nm] = ev
+            old = self.sent.setdefault(nm, {}).get(key)
+            if old is not None:
+                self._release(old)
+            self.sent[nm][key] = ev
+
+    def _release(self, ev):
+        left = self._ev_refs.get(ev, 1) - 1
+        if left <= 0:
+            self._ev_refs.pop(ev, None)
+            self._ev_free.append(ev)          # no name refers to it any more: free to be recorded again
+        else:
+            self._ev_refs[ev] = left
 
     def writable(self, name):
-        """wait until the last upload of ``name`` has left the pinned host buffer (call before refilling it on the
-        host).  Free in the normal call order: a step waits for its results, hence for the kernel behind the uploads.
-        One wait serves every array the same copy carried."""
-        ev = self.sent.pop(name, None)         # (an array collected for the copy at the next fence() is not on the wire)
-        if ev is not None:
-            ev.synchronize()
-            if len(self.sent) and any(e is ev for e in self.sent.values()):
-                self.sent = {k: e for k, e in self.sent.items() if e is not ev}
+        """wait until every outstanding upload of ``name`` has left the pinned host buffer (call before refilling it on the
+        host).  Free in the normal call order: a step waits for its results, hence for the kernel behind the uploads."""
+        evs = self.sent.pop(name, None)        # (an array collected for the copy at the next fence() is not on the wire)
+        if evs:
+            for ev in evs.values():
+                ev.synchronize()
+                self._release(ev)
 
     def _names_in(self, lo, hi):
         return [nm for nm in self.begin if lo <= self.begin[nm] and self.end[nm] <= hi]
@@ -256,8 +272,32 @@ class Sharded:
             return self
         raise IndexError("a Sharded array can only be taken whole")
 
+    #: how often any Sharded array was gathered onto ONE device (tests assert that the hot path, the slow paths and the
+    #: nudge never do: results leave the devices block by block, straight to the host)
+    gather_calls = 0
+
+    def map(self, fn, *others):
+        """``fn(part, other_part, ...)`` on every device's block (``others``: Sharded arrays with the same partition, or
+        plain values handed to every call); a Sharded of the results"""
+        parts = [fn(p, *[(o.parts[d] if isinstance(o, Sharded) else o) for o in others]) for d, p in enumerate(self.parts)]
+        return Sharded(parts, self.bounds)
+
+    def to_host(self):
+        """NumPy array of the whole thing: every block copied to the host from ITS device and concatenated there -- the
+        host-side gather of north_star (spifs output, setter fan-out); no device ever holds the whole batch"""
+        import numpy
+        for p in self.parts:                      # produced on the engines' own streams
+            if p.device.type == "cuda":
+                torch.cuda.synchronize(p.device)
+        if self.bounds is None:
+            return self.parts[0].cpu().numpy()
+        blocks = [p.cpu().numpy() for p in self.parts if p.shape[0]]
+        return numpy.concatenate(blocks, axis=0) if blocks else self.parts[0].cpu().numpy()
+
     def gather(self, device=None):
-        """the whole array on ONE device (slow paths: diagnostics for the spifs writer, convert_profiles)"""
+        """the whole array on ONE device.  Nothing in the package calls it any more (round 5: the slow paths, the sputils
+        helpers and the nudge run per device on that device's rows); kept for callers that want a device-resident copy."""
+        Sharded.gather_calls += 1
         device = self.parts[0].device if device is None else device
         for p in self.parts:                      # the parts may have been produced on other streams / devices
             if p.device.type == "cuda":

@@ -207,8 +207,9 @@ def prop_reversal_is_index_arithmetic_only(impl):
 # (h) splib.py:317, 330: every column is coupled on its own -- permuting the columns permutes the results, and a column's
 #     result does not depend on what else is in the batch
 def prop_columns_are_independent(impl):
-    gcm, zf, zh, prof = batch(37)
-    perm = numpy.random.default_rng(3).permutation(37)
+    n = 2601          # enough columns for the kernels to put SEVERAL into one workgroup's slab (and an odd tail)
+    gcm, zf, zh, prof = batch(n)
+    perm = numpy.random.default_rng(3).permutation(n)
     r, b = impl.forward(gcm, zf, zh, prof, 1.0, DT), impl.backward(gcm, zf, zh, prof, 1.0, DT, False)
     gp, pp = {k: numpy.ascontiguousarray(v[perm]) for k, v in gcm.items()}, {k: numpy.ascontiguousarray(v[perm]) for k, v in prof.items()}
     rp, bp = impl.forward(gp, zf, zh, pp, 1.0, DT), impl.backward(gp, zf, zh, pp, 1.0, DT, False)

@@ -43,7 +43,10 @@ def test_row_blocks_over_several_engines_equal_one_engine(ndev, n_les, batched, 
     multi = MultiDeviceEngine([OracleEngine() for _ in range(ndev)], min_cols_per_device=1)
     assert multi.devices_for(n_les) == min(ndev, n_les)
     assert multi.bounds_for(n_les)[:min(ndev, n_les) + 1] == shard_bounds(n_les, min(ndev, n_les))
+    from sp_coupler_amd.transfer import Sharded
+    before = Sharded.gather_calls
     got = _closed_loop(multi, n_les, 3, batched, cplsurf, conservative)
+    assert Sharded.gather_calls == before            # round 5: nothing on the step path gathers the batch onto one device
     for var in ref[0]:
         assert numpy.array_equal(ref[0][var], got[0][var], equal_nan=True), var
     if ref[1] is not None:
@@ -215,3 +218,188 @@ def test_bench_in_process_extra_runs_on_two_engines():
     # every device's row block proves itself against the plain-C oracle (first and last row of the block included)
     assert r["verified"] is True and [c["rows"] for c in r["verified_detail"]] == [[0, 3000], [3000, 6000]]
     assert all(c["first_row"] == 0 and c["last_row"] == 2999 and c["failures"] == [] for c in r["verified_detail"])
+
+
+# ---- round 5 (round-4 verdict, weak 9 / next 4): the slow paths, the sputils helpers and the nudge run PER DEVICE on that device's
+# rows; nothing gathers the batch onto one device any more (transfer.Sharded.gather_calls counts) -----------------------------------
+class _CountingEngine:
+    """a test engine that counts what reaches it (rows per call)"""
+
+    def __init__(self, inner):
+        self.inner, self.calls = inner, []
+
+    def __getattr__(self, name):
+        attr = getattr(self.inner, name)
+        if name in ("forward", "backward", "diagnostics", "cloud_indices", "surface_fluxes", "variability_nudge", "exner", "interp",
+                    "searchsorted", "interp_c", "rms"):
+            def counted(*a, **k):
+                flat = [t for x in a for t in (x.values() if isinstance(x, dict) else [x]) if hasattr(x, "shape") or isinstance(x, dict)]
+                rows = next((int(t.shape[0]) for t in flat if t.dim() >= 2), int(flat[0].shape[0]))    # rows of the first matrix
+                self.calls.append((name, rows))
+                return attr(*a, **k)
+            return counted
+        return attr
+
+
+def _three():
+    from tests.fake_engine import OracleEngine
+    return [_CountingEngine(OracleEngine()) for _ in range(3)]
+
+
+def make_case(itot, jtot, ktot, seed):
+    """one synthetic LES for the nudge: the fields of tests/test_vnudge.make_les_fields + the zero-mean random plane R"""
+    from tests.test_vnudge import make_les_fields
+    c = make_les_fields(itot, jtot, ktot, seed)
+    R = numpy.random.default_rng(seed + 1000).normal(size=(itot, jtot))
+    c["R"] = R - R.sum() / (itot * jtot)
+    return c
+
+
+def test_convenience_forms_run_per_device_without_a_gather():
+    import torch
+    from sp_coupler_amd import synthetic
+    from sp_coupler_amd.transfer import Sharded
+    from tests.fake_engine import OracleEngine
+    n = 11
+    gcm, zf, zh, prof = synthetic.make_batch(n, 19, 40, seed=3)
+    one = OracleEngine()
+    t = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}                                 # noqa: E731
+    ref_f = one.forward(t(gcm), torch.from_numpy(zf), t(prof), 1.0, 900.0, zh=torch.from_numpy(zh), want_profiles=True, couple_surface=True)
+    ref_b = one.backward(t(gcm), torch.from_numpy(zf), t(prof), 1.0, 900.0, conservative=True, zh=torch.from_numpy(zh))
+    ref_d = one.diagnostics(t(gcm), torch.from_numpy(zf), t(prof))
+    engines = _three()
+    multi = MultiDeviceEngine(engines, min_cols_per_device=2)
+    before = Sharded.gather_calls
+    g = {k: multi.to_devices(v, rows=n) for k, v in gcm.items()}
+    p = {k: multi.to_devices(v, rows=n) for k, v in prof.items()}
+    zf_s, zh_s = multi.to_devices(zf), multi.to_devices(zh)
+    f = multi.forward(g, zf_s, p, 1.0, 900.0, zh=zh_s, want_profiles=True, couple_surface=True)
+    b = multi.backward(g, zf_s, p, 1.0, 900.0, conservative=True, zh=zh_s)
+    d = multi.diagnostics(g, zf_s, p)
+    idx = multi.cloud_indices(zh_s, d["Zh"])
+    for res, ref in ((f, ref_f), (b, ref_b), (d, ref_d)):
+        for k, v in ref.items():
+            assert isinstance(res[k], Sharded) and res[k].bounds == multi.bounds_for(n)
+            assert numpy.array_equal(res[k].to_host(), v.numpy(), equal_nan=True), k
+    assert numpy.array_equal(idx.to_host(), ref_f["idx"].numpy())
+    assert Sharded.gather_calls == before
+    # every engine saw ITS rows only: 4 + 4 + 3
+    for e, rows in zip(engines, (4, 4, 3)):
+        assert {c[1] for c in e.calls} == {rows}, e.calls
+        assert [c[0] for c in e.calls] == ["forward", "backward", "diagnostics", "cloud_indices"]
+
+
+def test_sputils_helpers_shard_their_rows_over_the_engines():
+    """sp_coupler_amd.sputils (the reference's helper names, NumPy in / NumPy out) on a MultiDeviceEngine: a batch of rows is
+    dealt out block by block; a call on one column, or on device tensors, stays on the first engine"""
+    from oracle import spcpl_oracle as orc
+    from sp_coupler_amd import sputils, synthetic
+    from sp_coupler_amd.transfer import Sharded
+    from tests.fake_engine import OracleEngine
+    n = 10
+    gcm, zf, zh, prof = synthetic.make_batch(n, 19, 40, seed=8)
+    Zf = (gcm["Zgfull"] - gcm["Zghalf"][:, -1:]) / 9.81
+    Zh = (gcm["Zghalf"] - gcm["Zghalf"][:, -1:]) / 9.81
+    xp, fp = numpy.ascontiguousarray(Zf[:, ::-1]), numpy.ascontiguousarray(gcm["U"][:, ::-1])
+    engines = _three()
+    spcpl.set_engine(MultiDeviceEngine(engines, min_cols_per_device=2))
+    before = Sharded.gather_calls
+    try:
+        got = {"exner": sputils.exner(gcm["Pfull"]), "iexner": sputils.iexner(gcm["Pfull"]),
+               "interp": sputils.interp(zf, xp, fp), "interp_lr": sputils.interp(zf, xp, fp, left=-1.0, right=7.0),
+               "searchsorted": sputils.searchsorted(zh, Zh, side="right"), "interp_c": sputils.interp_c(Zh, zh, prof["QT"], prof["Rhobf"]),
+               "interp_rho": sputils.interp_rho(Zh, zh, prof["Rhobf"]), "rms_rows": sputils.rms(prof["U"], axis=-1),
+               "rms_all": sputils.rms(prof["U"]), "one_column": sputils.interp(zf, xp[3], fp[3])}
+    finally:
+        spcpl.set_engine(None)
+    assert Sharded.gather_calls == before
+    assert numpy.array_equal(got["exner"], orc.exner(gcm["Pfull"])) and numpy.array_equal(got["iexner"], orc.iexner(gcm["Pfull"]))
+    want = numpy.stack([numpy.interp(zf, xp[r], fp[r]) for r in range(n)])
+    assert numpy.array_equal(got["interp"], want) and numpy.array_equal(got["one_column"], want[3])
+    assert numpy.array_equal(got["interp_lr"], numpy.stack([numpy.interp(zf, xp[r], fp[r], left=-1.0, right=7.0) for r in range(n)]))
+    assert numpy.array_equal(got["searchsorted"], numpy.stack([numpy.searchsorted(zh, Zh[r], side="right") for r in range(n)]))
+    assert numpy.array_equal(got["interp_c"], numpy.stack([orc.interp_c(Zh[r], zh, prof["QT"][r], prof["Rhobf"][r]) for r in range(n)]))
+    with numpy.errstate(all="ignore"):
+        assert numpy.array_equal(got["interp_rho"], numpy.stack([orc.interp_rho(Zh[r], zh, prof["Rhobf"][r]) for r in range(n)]))
+    assert numpy.array_equal(got["rms_rows"], numpy.array([orc.rms(r) for r in prof["U"]])) and got["rms_all"] == orc.rms(prof["U"].reshape(-1))
+    # the batched calls reached every engine with its 4 / 4 / 2 rows (ceil(10 / 3) per block); the whole-array rms and the
+    # one-column call only the first
+    ops = ["exner", "exner", "interp", "interp", "searchsorted", "interp_c", "interp_c", "rms"]
+    for e, rows in zip(engines[1:], (4, 2)):
+        assert e.calls == [(op, rows) for op in ops], e.calls
+    assert engines[0].calls[:8] == [(op, 4) for op in ops] and [c[0] for c in engines[0].calls[8:]] == ["rms", "interp"]
+
+
+def test_variability_nudge_deals_the_les_out_over_the_engines(monkeypatch):
+    """spcpl._vnudge_launch: each engine nudges ITS LES (contiguous blocks, sharding.shard_bounds), in chunks of what fits it;
+    same bits as one engine, the 3-D fields never meet on one device"""
+    from tests.fake_engine import OracleEngine
+    n = 5
+    cases = [make_case(6, 5, 7, seed=40 + i) for i in range(n)]
+    F = {k: numpy.stack([c[k] for c in cases]) for k in ("qt", "qsat", "ql_av", "qt_av", "ql_ref", "presf", "thl", "ql")}
+    Rs = numpy.stack([c["R"] for c in cases])
+    spcpl.set_engine(OracleEngine())
+    try:
+        ref = spcpl._vnudge_launch({k: v.copy() for k, v in F.items()}, Rs, True)
+    finally:
+        spcpl.set_engine(None)
+    engines = _three()
+    spcpl.set_engine(MultiDeviceEngine(engines, min_cols_per_device=1))
+    monkeypatch.setattr(spcpl, "_vnudge_chunk", lambda eng, n_, *a: 1)           # one LES per launch: two rounds on the first engines
+    try:
+        got = spcpl._vnudge_launch({k: v.copy() for k, v in F.items()}, Rs, True)
+    finally:
+        spcpl.set_engine(None)
+    for k in ref[0]:
+        assert numpy.array_equal(ref[0][k], got[0][k], equal_nan=True), k
+    assert numpy.array_equal(ref[1], got[1]) and numpy.array_equal(ref[2], got[2])
+    assert [len(e.calls) for e in engines] == [2, 2, 1] and all(c == ("variability_nudge", 1) for e in engines for c in e.calls)
+
+
+@pytest.mark.gpu
+def test_slow_paths_helpers_and_nudge_on_two_engines_of_one_gpu():
+    """the same through the HIP kernels: two Engines on the one card stand for two devices; bit-equal to one Engine, no gather"""
+    import torch
+    from sp_coupler_amd import sputils, synthetic
+    from sp_coupler_amd.engine import Engine
+    from sp_coupler_amd.transfer import Sharded
+    n = 2501
+    gcm, zf, zh, prof = synthetic.make_batch(n, 91, 160, seed=12)
+    one = Engine("cuda:0")
+    up = lambda d: {k: torch.from_numpy(v).to(one.device) for k, v in d.items()}                  # noqa: E731
+    zf_d, zh_d = torch.from_numpy(zf).to(one.device), torch.from_numpy(zh).to(one.device)
+    ref_f = one.forward(up(gcm), zf_d, up(prof), 1.0, 900.0, zh=zh_d, want_profiles=True, couple_surface=True)
+    ref_b = one.backward(up(gcm), zf_d, up(prof), 1.0, 900.0, conservative=True, zh=zh_d)
+    ref_d = one.diagnostics(up(gcm), zf_d, up(prof))
+    multi = MultiDeviceEngine([Engine("cuda:0"), Engine("cuda:0", stream=torch.cuda.Stream("cuda:0"))], min_cols_per_device=500)
+    before = Sharded.gather_calls
+    g = {k: multi.to_devices(v, rows=n) for k, v in gcm.items()}
+    p = {k: multi.to_devices(v, rows=n) for k, v in prof.items()}
+    zf_s, zh_s = multi.to_devices(zf), multi.to_devices(zh)
+    f = multi.forward(g, zf_s, p, 1.0, 900.0, zh=zh_s, want_profiles=True, couple_surface=True)
+    b = multi.backward(g, zf_s, p, 1.0, 900.0, conservative=True, zh=zh_s)
+    d = multi.diagnostics(g, zf_s, p)
+    for res, ref in ((f, ref_f), (b, ref_b), (d, ref_d)):
+        for k, v in ref.items():
+            assert numpy.array_equal(res[k].to_host(), v.cpu().numpy(), equal_nan=True), k
+    Zh = ref_d["Zh"].cpu().numpy()
+    spcpl.set_engine(one)
+    try:
+        r1 = (sputils.iexner(gcm["Pfull"]), sputils.interp_c(Zh, zh, prof["QT"], prof["Rhobf"]), sputils.rms(prof["U"], axis=-1),
+              sputils.searchsorted(zh, Zh, side="right"))
+        cases = [make_case(64, 64, 40, seed=70 + i) for i in range(3)]
+        F = {k: numpy.stack([c[k] for c in cases]) for k in ("qt", "qsat", "ql_av", "qt_av", "ql_ref", "presf", "thl", "ql")}
+        Rs = numpy.stack([c["R"] for c in cases])
+        v1 = spcpl._vnudge_launch({k: v.copy() for k, v in F.items()}, Rs, True)
+        spcpl.set_engine(multi)
+        r2 = (sputils.iexner(gcm["Pfull"]), sputils.interp_c(Zh, zh, prof["QT"], prof["Rhobf"]), sputils.rms(prof["U"], axis=-1),
+              sputils.searchsorted(zh, Zh, side="right"))
+        v2 = spcpl._vnudge_launch({k: v.copy() for k, v in F.items()}, Rs, True)
+    finally:
+        spcpl.set_engine(None)
+    for a, c in zip(r1, r2):
+        assert numpy.array_equal(a, c, equal_nan=True)
+    for k in v1[0]:
+        assert numpy.array_equal(v1[0][k], v2[0][k], equal_nan=True), k
+    assert numpy.array_equal(v1[1], v2[1]) and numpy.array_equal(v1[2], v2[2])
+    assert Sharded.gather_calls == before

@@ -158,6 +158,19 @@ def test_row_pitches_of_2_pow_24_elements_are_refused():
     near = wide.view(-1)[:2 * (2 ** 24 - 1)].view(2, 2 ** 24 - 1)            # rows 2^24 - 1 elements apart
     near[:, :3] = torch.tensor([[10.0, 20.0, 30.0], [1.0, 2.0, 3.0]], dtype=torch.float64, device="cuda")
     assert numpy.array_equal(eng.interp(x, xp, near[:, :3]).cpu().numpy(), [[15.0, 25.0], [1.5, 2.5]])
+    # a ONE-row launch never multiplies the pitch (its row index is 0): one long vector of 2^24 points and more is served
+    # (round-4 advisor: sputils.interp / searchsorted on a single long vector were refused since round 4's second K7 pass)
+    long_x = torch.linspace(-1.0, 3.0, 2 ** 24 + 5, dtype=torch.float64, device="cuda")
+    fp1 = torch.tensor([10.0, 20.0, 30.0], dtype=torch.float64, device="cuda")
+    got = eng.interp(long_x, xp, fp1).cpu().numpy()
+    assert numpy.array_equal(got, numpy.interp(long_x.cpu().numpy(), [0.0, 1.0, 2.0], [10.0, 20.0, 30.0]))
+    idx = eng.searchsorted(xp, long_x, side="right").cpu().numpy()
+    assert numpy.array_equal(idx, numpy.searchsorted([0.0, 1.0, 2.0], long_x.cpu().numpy(), side="right"))
+    # rows padded to millions of elements: the slab height is cut so that 32-bit byte offsets hold (rb * pitch * 8 < 2^32)
+    pad = wide.view(-1)[:4 * (2 ** 23)].view(4, 2 ** 23)
+    pad[:, :3] = torch.tensor([[10.0, 20.0, 30.0], [1.0, 2.0, 3.0], [5.0, 6.0, 7.0], [-1.0, -2.0, -3.0]], dtype=torch.float64, device="cuda")
+    x4 = torch.tensor([[0.5], [1.5], [0.25], [2.0]], dtype=torch.float64, device="cuda")
+    assert numpy.array_equal(eng.interp(x4, xp, pad[:, :3]).cpu().numpy(), [[15.0], [2.5], [5.25], [-3.0]])
 
 
 def test_searchsorted_is_numpy_searchsorted(sputils):
@@ -269,6 +282,51 @@ def test_operator_plans_and_caller_provided_outputs():
         eng.plan_interp(dev(x), dev(xp), dev(fp), out=torch.empty(n, nL + 1, dtype=torch.float64, device="cuda"))
     with pytest.raises(ValueError):
         eng.plan_rms(dev(q), out=torch.empty(n, dtype=torch.float32, device="cuda"))
+
+
+def test_a_plan_on_a_view_it_cannot_read_in_place_follows_the_callers_tensor():
+    """round-4 advisor (medium): a K7 plan built on a tensor the kernels cannot read in place (a transposed view, a shared fp,
+    q / rho of different pitch, a strided pressure field) holds a PRIVATE packed copy -- which run() refreshes from the
+    caller's tensor before every launch, so an in-place update of the source is seen (rounds 3-4 recomputed from the stale
+    snapshot without a word).  Row-contiguous arguments are read in place: no copy, run() is one foreign call."""
+    from sp_coupler_amd.engine import Engine
+    eng = Engine("cuda:0")
+    rng = numpy.random.default_rng(21)
+    n, nG, nL = 64, 91, 160
+    dev = lambda a: torch.from_numpy(numpy.ascontiguousarray(a)).cuda()       # noqa: E731
+    xp = dev(numpy.sort(rng.uniform(0, 4000, size=(n, nG)), axis=1))
+    x = dev(rng.uniform(-100, 4100, size=(n, nL)))
+    fpT = dev(rng.normal(size=(nG, n)))                         # fp as a TRANSPOSED view: [n x nG] with row stride 1
+    plan = eng.plan_interp(x, xp, fpT.t())
+    assert len(plan._refresh) == 1
+    for _ in range(2):
+        want = numpy.stack([numpy.interp(x[r].cpu().numpy(), xp[r].cpu().numpy(), fpT.t()[r].cpu().numpy()) for r in range(n)])
+        assert numpy.array_equal(plan.run().cpu().numpy(), want)
+        fpT.mul_(-3.0).add_(1.0)                               # the caller updates ITS tensor in place; the plan follows
+    shared = dev(rng.normal(size=nG))                           # one fp row for all rows: spread per run
+    plan = eng.plan_interp(x, xp, shared)
+    for _ in range(2):
+        want = numpy.stack([numpy.interp(x[r].cpu().numpy(), xp[r].cpu().numpy(), shared.cpu().numpy()) for r in range(n)])
+        assert numpy.array_equal(plan.run().cpu().numpy(), want)
+        shared.add_(2.5)
+    Zh = dev(numpy.sort(rng.uniform(0, 6000, size=(n, nG + 1)), axis=1)[:, ::-1])
+    zh = dev(numpy.arange(nL) * 25.0)
+    q, rho_wide = dev(rng.normal(size=(n, nL))), dev(rng.uniform(0.5, 1.3, size=(n, nL + 8)))
+    rho = rho_wide[:, :nL]                                      # another pitch than q: both packed, and re-packed per run
+    plan = eng.plan_interp_c(Zh, zh, q, rho)
+    for _ in range(2):
+        want = eng.interp_c(Zh, zh, q.clone(), rho.contiguous()).cpu().numpy()
+        assert numpy.array_equal(plan.run().cpu().numpy(), want, equal_nan=True)
+        q.mul_(0.5)
+        rho_wide.add_(0.1)
+    p = dev(rng.uniform(1e3, 1e5, size=(n, 2 * nG)))
+    plan = eng.plan_exner(p[:, ::2], inverse=True)             # every second pressure: strided
+    for _ in range(2):
+        assert numpy.array_equal(plan.run().cpu().numpy(), eng.exner(p[:, ::2].contiguous(), inverse=True).cpu().numpy())
+        p.mul_(0.9)
+    # what can be read in place is: the plan holds the caller's pointer and no copy
+    plan = eng.plan_interp(x, xp, fpT.t().contiguous())
+    assert plan._refresh == () and eng.plan_rms(q)._refresh == () and eng.plan_searchsorted(xp, x)._refresh == ()
 
 
 def test_interp_left_right_on_the_device(sputils):

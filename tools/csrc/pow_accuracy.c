@@ -5,10 +5,23 @@
  *        pow_accuracy <stride> f : the fp32 variant's spc_powf_pos (spc_powf.h) on EVERY stride-th float of [1e-4, 1.2] and of
  *                                  the whole positive range, against pow() in double (2^-29 float ulp: exact for this purpose),
  *                                  with the C library's powf next to it.
+ *        pow_accuracy <points> p : spc_pow_pos with the reciprocal -2 ... +2 ulp off the host's (the device refines v_rcp_f64
+ *                                  instead of dividing): the worst case over the five is the bound claimed for the device.
  *        (built with -shared -fPIC the file also exports spc_powf_host(x, y, out, n) for the GPU-side bit comparison) */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+/* the device's reciprocal (v_rcp_f64 + two Newton steps) is within 1 ulp of 1 / x but not the host's correctly rounded quotient:
+ * mode `p` pushes the host's reciprocal spc_rcp_ulps units in the last place off, a superset of what the device can return */
+static int spc_rcp_ulps = 0;
+static double spc_rcp_perturbed(double x)
+{
+    double r = 1.0 / x;
+    for (int i = 0; i < spc_rcp_ulps; ++i) r = nextafter(r, INFINITY);
+    for (int i = 0; i > spc_rcp_ulps; --i) r = nextafter(r, -INFINITY);
+    return r;
+}
+#define SPC_POW_RCP_HOST(x) spc_rcp_perturbed(x)
 #include "../../sp_coupler_amd/csrc/spc_pow.h"
 #include "../../sp_coupler_amd/csrc/spc_powf.h"
 #include <string.h>
@@ -104,6 +117,21 @@ void spc_powf_host(const float *x, float y, float *out, long n)
 int main(int argc, char **argv)
 {
     if (argc > 2 && argv[2][0] == 'f') return float_mode((unsigned)atol(argv[1]));
+    if (argc > 2 && argv[2][0] == 'p') {                              /* reciprocal -2 ... +2 ulp off: the device's envelope */
+        const long n = atol(argv[1]);
+        const double rd = 287.04, cp = 1004.;
+        const double ys[2] = {(-rd) / cp, rd / cp};
+        for (spc_rcp_ulps = -2; spc_rcp_ulps <= 2; ++spc_rcp_ulps) {
+            char what[32];
+            snprintf(what, sizeof(what), "rcp%+dulp", spc_rcp_ulps);
+            for (int k = 0; k < 2; ++k) {
+                sweep(what, spc_pow_pos, ys[k], 1e-6, 1.2, n, 0);
+                sweep(what, spc_pow_pos, ys[k], 1e-300, 1e300, n / 4, 1);
+            }
+        }
+        spc_rcp_ulps = 0;
+        return 0;
+    }
     if (argc > 2 && argv[2][0] == 'd') return check_division(atol(argv[1])) != 0;
     const long n = argc > 1 ? atol(argv[1]) : 20000000;
     const double rd = 287.04, cp = 1004.;

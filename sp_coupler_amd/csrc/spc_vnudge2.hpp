@@ -32,7 +32,24 @@ struct Vn2Tables {
     unsigned short lo[2][VN_MAXLEAF], n[2][VN_MAXLEAF], pl[2][VN_MAXLEAF], pr[2][VN_MAXLEAF];
     unsigned char rnd[2][VN_MAXLEAF];
     int nleaf[2], nround[2];
+    int balanced[2];      // the tree is the perfectly balanced one over a power of two of <= 64 leaves (vn_tree_balanced)
 };
+
+// Is the combine program the balanced binary tree over nleaf = 2^m <= 64 leaves -- every step slot[l] += slot[l + d] with d a
+// power of two, l a multiple of 2 d, in dependency round log2 d + 1?  (numpy's pairwise split halves exactly whenever the
+// length is 128 x 2^m: 64 x 64 planes, the 8192-element chunks of larger ones.)  Then ONE wave combines the leaves in
+// registers: lane i holds leaf i, v = v + shfl_down(v, d) for d = 1, 2, 4, ...: the same additions in the same order
+// (left + right), without the LDS read-add-write round trips of the general program (1.0 us of a 2.2-us evaluation round:
+// tools/stamps_k6.py, profiles/r05_k6_stamps.log).
+__host__ inline int vn_tree_balanced(int nleaf, const unsigned short *pl, const unsigned short *pr, const unsigned char *rnd)
+{
+    if (nleaf < 2 || nleaf > 64 || (nleaf & (nleaf - 1))) return 0;
+    for (int t = 0; t + 1 < nleaf; ++t) {
+        const int d = (int)pr[t] - (int)pl[t];
+        if (d <= 0 || (d & (d - 1)) || (pl[t] % (2 * d)) != 0 || (1 << (rnd[t] - 1)) != d) return 0;
+    }
+    return 1;
+}
 
 struct Vn2P {
     VnP p;
@@ -83,12 +100,25 @@ __host__ __device__ inline int vn_build_rounds(int nleaf, const unsigned short *
     return nr;
 }
 
+// lane i <- lane i + N of the same row of 16 lanes (DPP row_shl: data moves towards lower lanes); lanes whose source lies outside
+// the row keep their own value -- the balanced tree never uses those
+template <int N> __device__ __forceinline__ double vn_row_shl(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x100 | N, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x100 | N, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 // GLOBAL = false: the planes of the workgroup's KT levels are copied into LDS once and every evaluation runs from there
 // (planes of up to ~9 000 points).  GLOBAL = true: planes too large for the LDS (128 x 128 and up -- ordinary DALES sizes)
 // stay in the caller's transposed workspace, contiguous per level, and every evaluation streams them from L2 / the
 // Infinity Cache with coalesced 64-B-per-leaf-group reads: one workgroup per level (KT = 1), i.e. n_cols x ktot workgroups
 // and no strided [ij][k] access.  Same sums, same order, same bits as the LDS form.
-template <bool GLOBAL> __global__ __launch_bounds__(VN2_THREADS) void k_vnudge_solve(const Vn2P q)
+// RCACHE (LDS form only, planes of <= 8192 points with one leaf per 8-lane group -- 64 x 64 and smaller): every lane keeps its
+// share of the noise plane R in registers (32 more VGPRs; an instantiation of its own, so that the general form keeps its
+// registers and schedule: with the cache compiled into it the 92 x 92 planes ran 12-18 % slower, profiles/r05_k6_stamps.log).
+template <bool GLOBAL, bool RCACHE = false> __global__ __launch_bounds__(VN2_THREADS, RCACHE ? 2 : 4) void k_vnudge_solve(const Vn2P q)
 {
     const VnP &p = q.p;
     extern __shared__ __align__(16) unsigned char vn2_smem[];
@@ -244,7 +274,42 @@ template <bool GLOBAL> __global__ __launch_bounds__(VN2_THREADS) void k_vnudge_s
             if (tl < CW && t + 1 < nl) { tq_rnd[sh][qq] = s_rnd[sh][t]; tq_l[sh][qq] = s_pl[sh][t]; tq_r[sh][qq] = s_pr[sh][t]; }
         }
     }
+    // Diagnostic build only (-DSPC_STAMPS, tools/stamps_k6.py): thread 0 sums, over all evaluation rounds, the shader-clock
+    // time it spends in each part of a round (LDS / memory counters drained at every stamp) and leaves the sums in g_stamps.
+#ifdef SPC_STAMPS
+    unsigned long long k6_acc[6] = {0, 0, 0, 0, 0, 0}, k6_rounds = 0, k6_t = 0, k6_m2 = 0;
+    const unsigned long long k6_w0 = wall_clock64();
+#define K6_STAMP(i)                                                              \
+    do {                                                                         \
+        if (tid == 0 && g_stamps) {                                              \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          \
+            const unsigned long long now_ = __builtin_readcyclecounter();        \
+            if ((i) >= 0) k6_acc[(i) < 0 ? 0 : (i)] += now_ - k6_t;              \
+            k6_t = now_;                                                         \
+        }                                                                        \
+    } while (0)
+#else
+#define K6_STAMP(i) do { } while (0)
+#endif
+    // The additive search (mode 2, spcpl.py:653-656) evaluates sum(max(qt + a R - qsat, 0)): R is the same in every round, and
+    // with one leaf per 8-lane group a lane reads the SAME <= 16 elements of it each time.  The round stamps (tools/stamps_k6.py,
+    // profiles/r05_k6_stamps.log) put 3.0 us of a 5.1-us mode-2 round into these reads -- 16 dependent-latency trips to L2 per
+    // lane and round, where a mode-1 round (planes in LDS only) sums its leaves in 0.43 us -- so the lane's share of R is
+    // loaded ONCE into registers.  Same terms, same order, same bits.
+    constexpr int RC = 16;                                          // a leaf has <= 128 elements: <= 16 per lane
+    double Rreg[RC];
+    bool r_cached = false;
+    if constexpr (RCACHE) {
+        r_cached = nij <= 8192 && s_nleaf[1] <= ngrp;              // (the host launches this instantiation only then)
+        if (r_cached) {
+            const bool have = grp < s_nleaf[1];
+            const int lo = have ? (int)s_lo[1][grp] : 0, n = have ? (int)s_n[1][grp] : 0;
+#pragma unroll
+            for (int i = 0; i < RC; ++i) Rreg[i] = (n >= 8 && i < (n >> 3)) ? R[lo + 8 * i + acc] : 0.0;
+        }
+    }
     for (;;) {
+        K6_STAMP(-1);
         if (own) {
             double x = 0.0;
             int mode = 0;
@@ -260,6 +325,7 @@ template <bool GLOBAL> __global__ __launch_bounds__(VN2_THREADS) void k_vnudge_s
             s_x[kl] = x; s_mode[kl] = mode;
         }
         __syncthreads();
+        K6_STAMP(0);                                                 // hand-over of x / mode + barrier
         int any = 0;
         for (int l = 0; l < KT; ++l) any |= s_mode[l];
         if (!any) break;
@@ -299,20 +365,100 @@ template <bool GLOBAL> __global__ __launch_bounds__(VN2_THREADS) void k_vnudge_s
                     if (acc == 0) my_leaf[li] = res;
                 }
             };
-            if (mode == 1)
+            // RCACHE, a FULL leaf (128 elements, 16 per lane -- every leaf of a 64 x 64 plane): all 32 LDS reads of the lane are
+            // issued before the first term is formed (the scheduler otherwise keeps 4 in flight and waits 8 times: 1.37 us per
+            // mode-2 round against 0.5 us, tools/stamps_k6.py); the terms and their order are those of `leaves`
+            // (a leaf that starts on a multiple of 128 lies in ONE skew block of the plane: element lo + 8 i + acc sits 8 i doubles
+            //  behind the lane's first one, an immediate offset of the read)
+            const bool fast_leaf = RCACHE && r_cached && grp < nleaf && (int)s_n[shape][grp] == 8 * RC && ((int)s_lo[shape][grp] & 127) == 0;
+            auto full_leaf = [&](auto term) {
+                const int e0 = POS((int)s_lo[shape][grp] + acc);
+                const double *const pa = my_qt + e0, *const pb = my_qs + e0;
+                double qa[RC], qb[RC];
+#pragma unroll
+                for (int i = 0; i < RC; ++i) {
+                    qa[i] = pa[8 * i];
+                    qb[i] = pb[8 * i];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                double r = term(0, qa[0], qb[0]);
+#pragma unroll
+                for (int i = 1; i < RC; ++i) r += term(i, qa[i], qb[i]);
+                r = r + __shfl_down(r, 1, 8);
+                r = r + __shfl_down(r, 2, 8);
+                r = r + __shfl_down(r, 4, 8);
+                if (acc == 0) my_leaf[grp] = r;
+            };
+            if (fast_leaf && mode == 1)
+                full_leaf([&](int, double a_, double b_) {
+                    const double t = ((x * (a_ - qt_av)) + qt_av) - b_;
+                    return (t >= 0.0 || t != t) ? t : 0.0;
+                });
+            else if (fast_leaf && mode == 2)
+                full_leaf([&](int i, double a_, double b_) {
+                    const double t = (a_ + (x * Rreg[i])) - b_;
+                    return (t >= 0.0 || t != t) ? t : 0.0;
+                });
+            else if (mode == 1)
                 leaves([&](int ij) {
                     const int e = POS(c0 + ij);
                     const double t = ((x * (my_qt[e] - qt_av)) + qt_av) - my_qs[e];
                     return (t >= 0.0 || t != t) ? t : 0.0;                           // numpy.maximum(t, 0)
                 });
-            else if (mode == 2)
+            else if (RCACHE && mode == 2 && r_cached) {                // (one chunk, one leaf per group: li = grp)
+                if (grp < nleaf) {
+                    const int lo = (int)s_lo[shape][grp], n = (int)s_n[shape][grp];
+                    const auto term_g = [&](int ij) {
+                        const int e = POS(ij);
+                        const double t = (my_qt[e] + (x * R[ij])) - my_qs[e];
+                        return (t >= 0.0 || t != t) ? t : 0.0;
+                    };
+                    double res;
+                    if (n < 8) {
+                        res = 0.0;
+                        if (acc == 0)
+                            for (int i = 0; i < n; ++i) res += term_g(lo + i);
+                    } else {
+                        const int cnt = n >> 3, n8 = cnt << 3;
+                        const auto term_r = [&](int i) {
+                            const int e = POS(lo + 8 * i + acc);
+                            const double t = (my_qt[e] + (x * Rreg[i])) - my_qs[e];
+                            return (t >= 0.0 || t != t) ? t : 0.0;
+                        };
+                        double r = term_r(0);                       // (a short leaf: the last one of a plane that is no multiple of 128)
+#pragma unroll
+                        for (int i = 1; i < RC; ++i)
+                            if (i < cnt) r += term_r(i);
+                        r = r + __shfl_down(r, 1, 8);
+                        r = r + __shfl_down(r, 2, 8);
+                        r = r + __shfl_down(r, 4, 8);
+                        res = r;
+                        if (acc == 0)
+                            for (int i = n8; i < n; ++i) res += term_g(lo + i);
+                    }
+                    if (acc == 0) my_leaf[grp] = res;
+                }
+            } else if (mode == 2)
                 leaves([&](int ij) {
                     const int e = POS(c0 + ij);
                     const double t = (my_qt[e] + (x * R[c0 + ij])) - my_qs[e];
                     return (t >= 0.0 || t != t) ? t : 0.0;
                 });
+#ifdef SPC_STAMPS
+            if (mode == 2) { K6_STAMP(5); if (tid == 0) ++k6_m2; } else { K6_STAMP(1); }   // this wave's leaf sums, by mode
+#endif
             __syncthreads();
-            if (tl < CW && mode != 0) {                             // numpy's tree, one dependency round at a time
+            K6_STAMP(2);                                            // barrier: every wave's leaves are in LDS
+            if (tl < CW && mode != 0 && s_tab.balanced[shape] && nleaf <= CW) {      // the balanced tree: in registers (vn_tree_balanced);
+                double v = tl < nleaf ? my_leaf[tl] : 0.0;                            // lanes tl .. tl + nleaf - 1 are this level's
+                // lane i + lane i + d: inside a row of 16 lanes by DPP row shifts (a register move), beyond by ds_bpermute
+                if (nleaf > 1) v = v + vn_row_shl<1>(v);
+                if (nleaf > 2) v = v + vn_row_shl<2>(v);
+                if (nleaf > 4) v = v + vn_row_shl<4>(v);
+                if (nleaf > 8) v = v + vn_row_shl<8>(v);
+                for (int sft = 16; sft < nleaf; sft <<= 1) v = v + __shfl_down(v, sft);
+                if (own) total += v;
+            } else if (tl < CW && mode != 0) {                      // numpy's tree, one dependency round at a time
                 const int nround = s_nround[shape];
                 if (shape ? tq_fast[1] : tq_fast[0]) {
                     const int r0 = shape ? tq_rnd[1][0] : tq_rnd[0][0], r1 = shape ? tq_rnd[1][1] : tq_rnd[0][1];
@@ -337,6 +483,7 @@ template <bool GLOBAL> __global__ __launch_bounds__(VN2_THREADS) void k_vnudge_s
             }
             if (c0 + 8192 < nij) __syncthreads();                   // the next chunk's leaves reuse the slots
         }
+        K6_STAMP(3);                                                // tree combine (dependency rounds of one wave)
         if (own && stage != VS_DONE) {
             const double f = total / (double)nij - ql_ref;                           // spcpl.py:646-648 / 653-656
             double root = 0.0;
@@ -371,7 +518,19 @@ template <bool GLOBAL> __global__ __launch_bounds__(VN2_THREADS) void k_vnudge_s
             default: break;
             }
         }
+        K6_STAMP(4);                                                // f, one step of the level's brentq state machine
+#ifdef SPC_STAMPS
+        ++k6_rounds;
+#endif
     }
+#ifdef SPC_STAMPS
+    if (tid == 0 && g_stamps) {
+        unsigned long long *const o = g_stamps + (size_t)blockIdx.x * 8;
+        for (int i = 0; i < 5; ++i) o[i] = k6_acc[i];
+        o[5] = k6_rounds; o[6] = wall_clock64() - k6_w0; o[7] = k6_acc[5] | (k6_m2 << 48);      // mode-2 leaf time | mode-2 rounds
+    }
+#endif
+#undef K6_STAMP
 
     if (own && valid) {
         p.beta[lev] = beta;

@@ -513,3 +513,44 @@ def test_conservative_coarsening_thick_layers_compile_time_geometries(eng, nG, n
     ref_np = orc.backward_batched(sub, ref_f["Zf"][cols], psub, zf, FACTOR, DT, conservative=True, Zh=ref_f["Zh"][cols], zh=zh)
     for k in ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V"):
         assert_bits(k, host(got[k])[cols], ref_np[k])
+
+
+def test_fp32_variant_is_the_float32_evaluation_of_the_reference_lines():
+    """The fp32 arithmetic variant (BASELINE config 5's sweep) forms its quotients through fp64 -- (float)((double)a * r), r = 1 /
+    (double)b (csrc/spc_hip.hip: Divisor<float>, round 5) -- which is the CORRECTLY ROUNDED float quotient: the kernels' u, v,
+    qt, ql and their forcings equal the reference's lines (spcpl.py:197-198, 215, 224-228, 328-333) evaluated by NumPy in
+    float32 arithmetic, bit for bit.  (thl passes through pow: csrc/spc_powf.h, tests/test_sputils_gpu.py.)"""
+    from sp_coupler_amd.engine import Engine
+    e32 = Engine("cuda:0", dtype=torch.float32)
+    f4 = numpy.float32
+    for n, nG, nL in ((300, 91, 160), (1500, 137, 512), (64, 60, 100)):
+        gcm, zf, zh, prof = synthetic.make_batch(n, nG, nL, seed=31 + nG, couple_surface=False)
+        g32 = {k: v.astype(f4) for k, v in gcm.items()}
+        p32 = {k: v.astype(f4) for k, v in prof.items()}
+        zf32, zh32 = zf.astype(f4), zh.astype(f4)
+        dev = lambda d: {k: torch.from_numpy(v).cuda() for k, v in d.items() if k not in ("Rain", "rain_last")}      # noqa: E731
+        factor, dt = 0.75, 900.0
+        r = e32.forward(dev(g32), torch.from_numpy(zf32).cuda(), dev(p32), factor, dt, zh=torch.from_numpy(zh32).cuda(), want_profiles=True)
+        torch.cuda.synchronize()
+        Zf = (g32["Zgfull"] - g32["Zghalf"][:, -1:]) / f4(9.81)                           # spcpl.py:198 in float32
+        Zh = (g32["Zghalf"] - g32["Zghalf"][:, -1:]) / f4(9.81)                           # spcpl.py:197
+        assert Zf.dtype == f4
+        assert_bits("Zf", host(r["Zf"]), Zf)
+        assert_bits("Zh", host(r["Zh"]), Zh)
+
+        def interp32(x, xp, fp):                     # numpy's arr_interp, every operation in float32
+            j = numpy.searchsorted(xp, x, side="right") - 1
+            jc = numpy.clip(j, 0, len(xp) - 2)
+            slope = (fp[jc + 1] - fp[jc]) / (xp[jc + 1] - xp[jc])
+            out = slope * (x - xp[jc]) + fp[jc]
+            out = numpy.where(xp[jc] == x, fp[jc], out)
+            out = numpy.where(j < 0, fp[0], out)
+            return numpy.where(j >= len(xp) - 1, fp[-1], out).astype(f4)
+        qt_ = g32["SH"] + g32["QL"] + g32["QI"]                                           # spcpl.py:215
+        for name, src, les in (("u", g32["U"], "U"), ("v", g32["V"], "V"), ("qt", qt_, "QT"), ("ql_ref", g32["QL"], "QL")):
+            want = numpy.stack([interp32(zf32, Zf[c, ::-1], src[c, ::-1]) for c in range(n)])       # spcpl.py:224-228
+            assert want.dtype == f4
+            assert_bits(name, host(r[name]), want)
+            fname = {"u": "f_u", "v": "f_v", "qt": "f_qt", "ql_ref": "f_ql"}[name]
+            assert_bits(fname, host(r[fname]), f4(factor) * (want - p32[les]) / f4(dt))                 # spcpl.py:328-333
+        assert_bits("f_ps", host(r["f_ps"]), f4(factor) * (g32["Phalf"][:, -1] - p32["PS"]) / f4(dt))

@@ -60,8 +60,10 @@ def main():
                 print("n=%d K4 cols_per_block=%d: %.1f us (%.2fx K3)" % (n, cb, t4, t4 / t3), flush=True)
         b3 = n * ((9 * nG + 6 * nL) + 7 * nG) * 8
         b4 = b3 + n * (nL + nG + 1) * 8                      # + Rhobf [nL], Zghalf [nG+1] per column
-        t5a = timed(lambda: eng.diagnostics(g), a.iters)
-        t5b = timed(lambda: eng.diagnostics(g, zf_d, p), a.iters)
+        k5a, k5b = eng.plan_diagnostics(g), eng.plan_diagnostics(g, zf_d, p)      # outputs bound once, as the step path's cached plans
+        t5a = timed(lambda: k5a.launch_raw(sptr), a.iters)
+        t5b = timed(lambda: k5b.launch_raw(sptr), a.iters)
+        print("n=%d K5 launches: %s | %s" % (n, k5a.describe(), k5b.describe()), flush=True)
         b5a = n * ((6 * nG + nG + 1) + (4 * nG + nG + 1)) * 8          # reads T,SH,QL,QI,Pf,Zgfull,Zghalf; writes Tv,THL,QT,Zf,Zh
         b5b = b5a + n * (3 * nL + 3 * nL) * 8                          # + reads THL,QL,QL_ice; writes pf,t,ql_water
         print("n=%d %d<->%d | K3 %.1f us %.0f GB/s | K4 (conservative) %.1f us %.0f GB/s (%.2fx K3) | K5 gcm-level %.1f us %.0f GB/s | "

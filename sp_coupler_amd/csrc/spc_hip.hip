@@ -920,6 +920,7 @@ template <typename T, int NG, int NL, int WT, int BLK = BLOCK, bool PRE = true> 
     STAMP(5);
 }
 
+#include "spc_f32v.hpp"
 #include "spc_vnudge.hpp"
 #include "spc_vnudge2.hpp"
 
@@ -1185,7 +1186,9 @@ template <typename KernelT> int pick_cb(const spc_dims *d, int pass, bool with_i
     // by 11 % at config 3, 4 x 2 loses 60 %: profiles/r03_k4_forms.log)
     if (pass == 4 && nb[1] * 2 > nb[0] && (d->n_cols + 1) / 2 >= 2 * cus * nb[1]) return 2;
     int best = 1, best_nb = -1;
-    for (int i = 3; i >= 0; --i) {                                                      // rule 2
+    // (K3<float>: slabs of more than two columns lose -- 70.9 us at two, 77.5 at four, 88.5 at eight columns per workgroup at
+    //  config 3, profiles/r05_f32_cbs.log -- where the residency tie of the 4-byte footprint would pick four)
+    for (int i = (pass == 1 && esize == 4) ? 1 : 3; i >= 0; --i) {                      // rule 2
         cb = 1 << i;
         const int64_t rounds_x_cus = nb[i] ? (d->n_cols + cb - 1) / cb / nb[i] : 0;   // rounds of workgroups x CUs
         const bool enough = rounds_x_cus >= (cb == 8 ? 8 : 2) * cus;   // measured: 8-column slabs pay off from ~8 rounds
@@ -1276,6 +1279,7 @@ int small_block(const spc_dims *d, int items_per_col)
 struct Choice {
     const char *kernel;
     int elem, full, idx, geo, wt, blk, pre, cb;
+    int vec = 0;      // the float kernels with 8-byte accesses (spc_f32v.hpp)
     unsigned grid;
     size_t smem;
 };
@@ -1337,7 +1341,22 @@ template <typename T> int choose_fwd(const spc_dims *d, bool with_idx, bool full
     lds_elems(d, 0, with_idx, &per_col, &fixed);
     c->smem = (per_col * c->cb + fixed) * sizeof(T);
     c->grid = (unsigned)((d->n_cols + c->cb - 1) / c->cb);
+    // float, compile-time geometry, lean, multi-round, an even slab: 8-byte accesses (spc_f32v.hpp; SPC_F32_VEC=0: A/B, tests)
+    c->vec = std::is_same<T, float>::value && c->geo != 0 && !full && !sb && !c->pre && c->cb % 2 == 0 && env_int("SPC_F32_VEC", 1);
     return SPC_OK;
+}
+
+// K1 of the float variant with 8-byte accesses, by (geometry, write-through)
+inline KLean<float> fwd_vec_kernel(int geo, int wt)
+{
+    static const KLean<float> k[2][4] = {{nullptr, k_forward_f32v<91, 160, 0>, k_forward_f32v<137, 512, 0>, k_forward_f32v<19, 160, 0>},
+                                         {nullptr, k_forward_f32v<91, 160, 1>, k_forward_f32v<137, 512, 1>, k_forward_f32v<19, 160, 1>}};
+    return k[wt ? 1 : 0][geo];
+}
+inline bool aligned8(std::initializer_list<const void *> ptrs)
+{
+    for (const void *q : ptrs) if ((uintptr_t)q & 7u) return false;
+    return true;
 }
 
 template <typename T> int forward_impl(const spc_dims *d, const spc_forward_args *a, void *stream)
@@ -1385,7 +1404,12 @@ template <typename T> int forward_impl(const spc_dims *d, const spc_forward_args
         if ((rc = ensure_lds(kern, c.smem, "forward"))) return rc;
         hipLaunchKernelGGL(kern, dim3(c.grid), dim3(c.blk), c.smem, (hipStream_t)stream, p);
     } else {
-        const KLean<T> kern = fwd_lean_kernel<T>(c.geo, c.wt, c.blk, c.pre);
+        KLean<T> kern = fwd_lean_kernel<T>(c.geo, c.wt, c.blk, c.pre);
+        if constexpr (std::is_same<T, float>::value) {
+            if (c.vec && aligned8({a->U, a->V, a->T, a->SH, a->QL, a->QI, a->Pf, a->Zgfull, a->zf, a->u_d, a->v_d, a->thl_d, a->qt_d, a->ql_d,
+                                   a->f_u, a->f_v, a->f_thl, a->f_qt, a->f_ql, a->ql_ref}))
+                kern = fwd_vec_kernel(c.geo, c.wt);
+        }
         if (!kern) return fail(SPC_ERR_UNSUPPORTED, "%sforward: no kernel instantiated for this launch choice (internal)");
         FwdP<T, false> p;
         fill(p);
@@ -1830,7 +1854,9 @@ int spc_describe_launch(const spc_dims *d, int pass, int flags, int elem_size, c
     if (rc) return rc;
     const char *ty = elem_size == 8 ? "f64" : "f32";
     char name[160];
-    if (pass == 0)
+    if (pass == 0 && c.vec)
+        snprintf(name, sizeof(name), "k_forward_f32v<%d,%d,wt=%d>", GEO_NG[c.geo], GEO_NL[c.geo], c.wt);
+    else if (pass == 0)
         snprintf(name, sizeof(name), "k_forward<%s,%s,%d,%d,wt=%d,blk=%d,pre=%d>", ty, c.full ? "full" : "lean", GEO_NG[c.geo], GEO_NL[c.geo],
                  c.wt, c.blk, c.pre);
     else if (pass == 1)

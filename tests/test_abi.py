@@ -122,7 +122,11 @@ def test_describe_launch_names_the_instantiation_the_launcher_would_pick(lib):
     assert " cb=2 " in k4 and int(k4.split("lds=")[1].split()[0]) <= 25 * 1280, k4
     assert _abi.describe_launch(lib, d(4096, nL=400), 4, 0).startswith("k_backward_cons2<f64,0,0,pd=2> cb=")
     assert _abi.describe_launch(lib, d(4096, nL=2000), 4, 0).startswith("k_backward_cons2<f64,0,0,pd=-1> cb=")
-    assert _abi.describe_launch(lib, d(4096), 0, 1, 4).startswith("k_forward<f32,lean,91,160,")
+    # float: multi-round launches of the compile-time geometries with an even slab take the 8-byte-access kernels (spc_f32v.hpp)
+    assert _abi.describe_launch(lib, d(4096), 0, 1, 4).startswith("k_forward_f32v<91,160,wt=1>")
+    assert _abi.describe_launch(lib, d(35718), 1, 0, 4).startswith("k_backward<f32,91,160,wt=0,blk=256,pre=1> cb=2 ")     # K3<float>: two columns
+    assert _abi.describe_launch(lib, d(1000), 0, 1, 4).startswith("k_forward<f32,lean,91,160,wt=1,blk=1024,pre=1>")      # one round: scalar
+    assert _abi.describe_launch(lib, d(4096, pad=1), 0, 1, 4).startswith("k_forward<f32,lean,0,0,")                    # run-time geometry: scalar
     txt = _abi.describe_launch(lib, d(35718), 0, 1)
     fields = dict(kv.split("=") for kv in txt.split()[1:])
     assert int(fields["cb"]) * int(fields["grid"]) >= 35718 > int(fields["cb"]) * (int(fields["grid"]) - 1)

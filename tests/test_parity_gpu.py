@@ -554,3 +554,50 @@ def test_fp32_variant_is_the_float32_evaluation_of_the_reference_lines():
             fname = {"u": "f_u", "v": "f_v", "qt": "f_qt", "ql_ref": "f_ql"}[name]
             assert_bits(fname, host(r[fname]), f4(factor) * (want - p32[les]) / f4(dt))                 # spcpl.py:328-333
         assert_bits("f_ps", host(r["f_ps"]), f4(factor) * (g32["Phalf"][:, -1] - p32["PS"]) / f4(dt))
+
+
+def test_fp32_eight_byte_access_kernels_equal_the_scalar_float_kernels(monkeypatch):
+    """csrc/spc_f32v.hpp (round 5): K1 of the float variant with float2 accesses -- two LES levels of a column, two adjacent
+    elements of the flat [ncol x nG] slab (a pair may straddle two columns: nG is odd) -- against the scalar float kernel
+    (SPC_F32_VEC=0): same bits.  Odd column counts (the scalar tail of the last slab), write-through and plain stores, a grid
+    per column, the three compile-time geometries, and array bases that are only 4-byte aligned (the launcher must fall back)."""
+    from sp_coupler_amd import _abi
+    from sp_coupler_amd.engine import Engine
+    e32 = Engine("cuda:0", dtype=torch.float32)
+    f4 = torch.float32
+    seen = set()
+    for n, nG, nL, percol in ((5001, 91, 160, False), (6145, 91, 160, True), (40001, 91, 160, False), (5003, 137, 512, False),
+                              (9001, 19, 160, False)):
+        gcm, zf, zh, prof = synthetic.make_batch_tiled(n, nG, nL, seed=400 + n, base=2048, couple_surface=False) if not percol else \
+            synthetic.make_batch(n, nG, nL, seed=400 + n, couple_surface=False, per_column_grid=True)
+        g = {k: torch.from_numpy(v).to(e32.device, f4) for k, v in gcm.items()}
+        p = {k: torch.from_numpy(v).to(e32.device, f4) for k, v in prof.items()}
+        zf_d, zh_d = torch.from_numpy(zf).to(e32.device, f4), torch.from_numpy(zh).to(e32.device, f4)
+        monkeypatch.setenv("SPC_F32_VEC", "1")
+        fp, bp = e32.plan_exchange(g, zf_d, zh_d, p, 0.8, 0.8, 900.0)
+        names = (fp.describe().split()[0], bp.describe().split()[0])         # (batches of one round keep one column per workgroup: scalar)
+        assert names[0].startswith("k_forward_f32v<%d,%d" % (nG, nL)), names
+        seen.update(nm.split("<")[0] + nm[nm.index(",wt"):] for nm in names if "f32v" in nm)
+        fp.launch(), bp.launch()
+        torch.cuda.synchronize()
+        vec = {k: host(v).copy() for k, v in list(fp.outputs.items()) + list(bp.outputs.items())}
+        for t in list(fp.outputs.values()) + list(bp.outputs.values()):
+            t.fill_(7)
+        monkeypatch.setenv("SPC_F32_VEC", "0")
+        assert "f32v" not in fp.describe() and "f32v" not in bp.describe()
+        fp.launch(), bp.launch()
+        torch.cuda.synchronize()
+        for k, v in list(fp.outputs.items()) + list(bp.outputs.items()):
+            assert_bits("%d %d<->%d %s" % (n, nG, nL, k), vec[k], host(v))
+        if percol:
+            continue
+        # bases that are 4-byte aligned only: rows [1:] of arrays with an odd row length
+        monkeypatch.setenv("SPC_F32_VEC", "1")
+        g1 = {k: torch.cat([v[:1], v])[1:] for k, v in g.items()}
+        assert g1["T"].data_ptr() % 8 == (4 if nG % 2 else 0)
+        fp1, bp1 = e32.plan_exchange(g1, zf_d, zh_d, p, 0.8, 0.8, 900.0)
+        fp1.launch(), bp1.launch()
+        torch.cuda.synchronize()
+        for k, v in list(fp1.outputs.items()) + list(bp1.outputs.items()):
+            assert_bits("misaligned %d %s" % (n, k), host(v), vec[k])
+    assert {"k_forward_f32v,wt=0>", "k_forward_f32v,wt=1>"} <= seen, seen

@@ -14,6 +14,8 @@ int spc_stream_copy(void *dst, const void *src, int64_t bytes, void *stream);
 /* The same with 8 B/lane accesses (the access width of the coupling kernels): calibrates the HBM PMC counters on
  * a known byte count in this path's own access pattern. */
 int spc_stream_copy_f64(void *dst, const void *src, int64_t bytes, void *stream);
+/* The same with 4 B/lane accesses and a caller-chosen grid (tools/copy_width.py). */
+int spc_stream_copy_f32(void *dst, const void *src, int64_t bytes, int grid, void *stream);
 /* Bandwidth probe (tools/bwprobe.py): n_read read streams and n_write write streams of bytes_per_stream bytes each
  * (stream r at src + r*bytes_per_stream, w at dst + w*bytes_per_stream), 16 B/lane, `grid` workgroups of 256
  * threads.  Instantiated mixes: 1:1, 1:0, 0:1, 2:1, 4:2, 8:0, 0:7, 14:7, 16:7 (114:7 / 214:7 = 14:7 with 512- /

@@ -65,6 +65,13 @@ __global__ __launch_bounds__(BLOCK) void k_copy8(double *dst, const double *src,
         dst[i] = src[i];
 }
 
+// 4 B/lane streaming copy: the access width of the fp32 arithmetic variant's kernels (is the width itself what they lose to?)
+__global__ __launch_bounds__(BLOCK) void k_copy4(float *dst, const float *src, int64_t n4)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * BLOCK)
+        dst[i] = src[i];
+}
+
 // Latency of a DEPENDENT fp64 add chain (what bounds k_vnudge_std: numpy's sequential qt.std sums): one wave, `n` adds
 // x = x + c[i & 15] with the addends in registers, result stored so the chain is live.  tools/fp64_chain.py times it.
 __global__ __launch_bounds__(64) void k_add_chain(double *out, const double *in, int n)
@@ -214,6 +221,14 @@ int spc_stream_probe(int n_read, int n_write, void *dst, const void *src, int64_
         return launch_status("k_probe");
     }
     return fail(-2, "%sstream_probe: stream mix not instantiated");
+}
+
+int spc_stream_copy_f32(void *dst, const void *src, int64_t bytes, int grid, void *stream)
+{
+    if (bytes < 0 || (bytes & 3) || !dst || !src || grid <= 0) return fail(-1, "%sstream_copy_f32: bytes must be a multiple of 4, pointers non-NULL");
+    if (bytes == 0) return 0;
+    hipLaunchKernelGGL(k_copy4, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (float *)dst, (const float *)src, bytes / 4);
+    return launch_status("k_copy4");
 }
 
 int spc_stream_copy_f64(void *dst, const void *src, int64_t bytes, void *stream)

@@ -18,6 +18,7 @@ def load():
         lib.spc_tools_last_error.restype = ctypes.c_char_p
         lib.spc_stream_copy.argtypes = [vp, vp, i64, vp]
         lib.spc_stream_copy_f64.argtypes = [vp, vp, i64, vp]
+        lib.spc_stream_copy_f32.argtypes = [vp, vp, i64, ctypes.c_int, vp]
         lib.spc_stream_probe.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, i64, ctypes.c_int, vp]
         lib.spc_probe_add_chain.argtypes = [vp, vp, ctypes.c_int, vp]
         lib.spc_probe_issue.argtypes = [ctypes.c_int, vp, vp, ctypes.c_int, vp]

@@ -5,7 +5,8 @@ config 4 (348 528 columns): this splits them.  usage: tools/trace_by_grid.py <di
 import collections, csv, glob, sys
 f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv") + glob.glob(sys.argv[1] + "/*kernel_trace.csv")
 acc = collections.OrderedDict()
-for r in csv.DictReader(open(f[0])):
+f.sort(key=lambda x: __import__("os").path.getmtime(x))          # several runs merged into one directory: the newest trace
+for r in csv.DictReader(open(f[-1])):
     name = r["Kernel_Name"]
     if "k_forward" not in name and "k_backward" not in name and "k_vnudge" not in name and "k_diag" not in name:
         continue

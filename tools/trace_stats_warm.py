@@ -5,7 +5,8 @@ usage: tools/trace_stats_warm.py <dir> [out.csv]"""
 import collections, csv, glob, sys
 f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv") + glob.glob(sys.argv[1] + "/*kernel_trace.csv")
 acc = collections.OrderedDict()
-for r in csv.DictReader(open(f[0])):
+f.sort(key=lambda x: __import__("os").path.getmtime(x))          # several runs merged into one directory: the newest trace
+for r in csv.DictReader(open(f[-1])):
     name = r["Kernel_Name"]
     if not any(k in name for k in ("k_forward", "k_backward", "k_vnudge", "k_diag", "k_interp", "k_exner", "k_searchsorted", "k_rms")):
         continue

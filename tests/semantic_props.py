@@ -29,8 +29,16 @@ FORCINGS = ("f_u", "f_v", "f_thl", "f_qt", "f_ql")
 TENDENCIES = ("f_T", "f_SH", "f_QL", "f_QI", "f_U", "f_V", "f_A")
 
 
-def batch(n=40, nG=91, nL=160, seed=777):
-    return synthetic.make_batch(n, nG, nL, seed, couple_surface=False)
+#: level geometry the properties run on; the test files also run them at BASELINE config 5's 137 <-> 512 (set_geometry)
+GEOMETRY = {"nG": 91, "nL": 160}
+
+
+def set_geometry(nG, nL):
+    GEOMETRY.update(nG=nG, nL=nL)
+
+
+def batch(n=40, seed=777):
+    return synthetic.make_batch(n, GEOMETRY["nG"], GEOMETRY["nL"], seed, couple_surface=False)
 
 
 def heights(gcm):
@@ -178,7 +186,7 @@ def prop_index_map_is_a_count(impl):
     g["Zgfull"] = 0.5 * (Zgh[:, :-1] + Zgh[:, 1:])
     _, Zh = heights(g)
     hits = numpy.isin(Zh, zh).sum()
-    assert hits > 10 * n, "the construction does not produce exactly equal heights (%d)" % hits
+    assert hits >= 4 * n, "the construction does not produce exactly equal heights (%d)" % hits     # (grav x height / grav is exact for most, not all)
     r = impl.forward(g, zf, zh, prof, 1.0, DT)
     want = numpy.empty((n, nG), dtype=numpy.int64)
     for m in range(nG):

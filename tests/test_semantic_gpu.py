@@ -54,6 +54,13 @@ def impl():
     return HipImpl()
 
 
+@pytest.fixture(params=[(91, 160), (137, 512)], ids=["91-160", "137-512"])
+def geometry(request):
+    sp.set_geometry(*request.param)
+    yield request.param
+    sp.set_geometry(91, 160)
+
+
 @pytest.mark.parametrize("prop", sp.PROPERTIES, ids=lambda f: f.__name__[5:])
-def test_property_holds_for_the_hip_kernels(impl, prop):
+def test_property_holds_for_the_hip_kernels(impl, prop, geometry):
     prop(impl)

@@ -32,8 +32,17 @@ class OracleImpl:
         return r["pf"], r["t"]
 
 
+@pytest.fixture(params=[(91, 160), (137, 512)], ids=["91-160", "137-512"])
+def geometry(request):
+    sp.set_geometry(*request.param)
+    yield request.param
+    sp.set_geometry(91, 160)
+
+
 @pytest.mark.parametrize("prop", sp.PROPERTIES, ids=lambda f: f.__name__[5:])
-def test_property_holds_for_the_oracle(prop):
+def test_property_holds_for_the_oracle(prop, geometry):
+    if geometry == (137, 512) and prop.__name__ == "prop_columns_are_independent":
+        pytest.skip("2 601 columns of 137 <-> 512 through the per-column Python oracle: minutes; covered at 91 <-> 160")
     prop(OracleImpl())
 
 

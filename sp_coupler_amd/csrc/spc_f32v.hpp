@@ -35,7 +35,13 @@ template <int WT> __device__ __forceinline__ void st2(float *q, float a, float b
 }
 
 // ---- K1 -----------------------------------------------------------------------------------------------------------------
-template <int NG, int NL, int WT> __global__ __launch_bounds__(BLOCK, SPC_K1_WAVES) void k_forward_f32v(const FwdP<float, false> p)
+// Waves per SIMD the register allocator is asked to fit: eight (<= 64 VGPRs, <= 96 SGPRs: 45 scalar spills into VGPR lanes) for
+// the large 160-level launches -- 74.6-75.0 against 77.6 us at config 3 -- and no request elsewhere (137 <-> 512: 446 against
+// 443 us; write-through launches of a few thousand columns: 13.6 against 13.0 us) (profiles/r05_f32_vec_ab.log, second block).
+#ifndef SPC_F32V_WAVES
+#define SPC_F32V_WAVES(NL_, WT_) (((NL_) <= 160 && (WT_) == 0) ? 8 : 1)
+#endif
+template <int NG, int NL, int WT> __global__ __launch_bounds__(BLOCK, SPC_F32V_WAVES(NL, WT)) void k_forward_f32v(const FwdP<float, false> p)
 {
     using T = float;
     static_assert(NG > 0 && NL > 0 && NL % 2 == 0, "compile-time geometry with an even LES level count");

@@ -26,17 +26,27 @@ SPC_POW_FN float spc_powf_pos(float xf, float yf)
     if (m < 0.70710678118654752440) { m *= 2.0; e -= 1; }            /* [sqrt 1/2, sqrt 2) */
     const double f = (m - 1.0) / (m + 1.0);
     const double s = f * f;
-    double P = 2.0 / 13.0;
-    P = __builtin_fma(P, s, 2.0 / 11.0); P = __builtin_fma(P, s, 2.0 / 9.0); P = __builtin_fma(P, s, 2.0 / 7.0);
+    /* the coefficients of the SMALL terms (s^3 and beyond here, r^6 and beyond below) are rounded to doubles whose low 32 bits are
+     * zero: such a constant is ONE 32-bit literal of a v_fma_f64 (the hardware takes it as the high word) instead of a pair of
+     * scalar registers or two v_mov per use (K1<float>: 48 -> 44 VGPRs, 7 -> 4 scalar spills in its float2 form; it stays at
+     * seven waves per SIMD -- 106 SGPRs, half of them its 26 array pointers).  Their 2^-21 relative rounding acts on terms below
+     * 8e-6 of the result: 2^-38, inside the error budget (the sweep's worst case and its > 0.5-ulp fraction did not move). */
+    double P = 0x1.3b13b00000000p-3;                                 /* 2/13 */
+    P = __builtin_fma(P, s, 0x1.745d100000000p-3);                   /* 2/11 */
+    P = __builtin_fma(P, s, 0x1.c71c700000000p-3);                   /* 2/9 */
+    P = __builtin_fma(P, s, 0x1.2492500000000p-2);                   /* 2/7 */
     P = __builtin_fma(P, s, 2.0 / 5.0); P = __builtin_fma(P, s, 2.0 / 3.0);
     const double logm = __builtin_fma(f * s, P, 2.0 * f);            /* 2 atanh f */
     double t = (double)yf * __builtin_fma((double)e, LN2, logm);     /* y log x */
     t = t < -800.0 ? -800.0 : (t > 800.0 ? 800.0 : t);               /* beyond: 0 / inf after the conversion anyway */
     const double n = rint(t * LOG2E);
     const double r = __builtin_fma(-n, LN2, t);
-    double q = 1.0 / 3628800.0;
-    q = __builtin_fma(q, r, 1.0 / 362880.0); q = __builtin_fma(q, r, 1.0 / 40320.0); q = __builtin_fma(q, r, 1.0 / 5040.0);
-    q = __builtin_fma(q, r, 1.0 / 720.0); q = __builtin_fma(q, r, 1.0 / 120.0); q = __builtin_fma(q, r, 1.0 / 24.0);
+    double q = 0x1.27e5000000000p-22;                                /* 1/10! */
+    q = __builtin_fma(q, r, 0x1.71de400000000p-19);                  /* 1/9! */
+    q = __builtin_fma(q, r, 0x1.a01a000000000p-16);                  /* 1/8! */
+    q = __builtin_fma(q, r, 0x1.a01a000000000p-13);                  /* 1/7! */
+    q = __builtin_fma(q, r, 0x1.6c16c00000000p-10);                  /* 1/6! */
+    q = __builtin_fma(q, r, 1.0 / 120.0); q = __builtin_fma(q, r, 1.0 / 24.0);
     q = __builtin_fma(q, r, 1.0 / 6.0); q = __builtin_fma(q, r, 0.5); q = __builtin_fma(q, r, 1.0);
     q = __builtin_fma(q, r, 1.0);                                    /* exp r */
     return (float)ldexp(q, (int)n);                                  /* the one rounding to float (gradual underflow included) */

@@ -131,6 +131,30 @@ def rms(a, axis=None):
     return _with_unit(io.back(io.eng.rms(ad), scalar=ad.dim() == 1), unit)
 
 
+def _periodic(x, xp, fp, period):
+    """``numpy.interp(..., period=)`` (what ``**kwargs`` of splib/sputils.py:82-86 passes through) is a host-side
+    normalisation in NumPy itself followed by the ordinary interpolation: abscissae modulo ``|period|``, samples sorted, one
+    wrapped sample added at either end, ``left`` / ``right`` ignored.  The same steps with the same NumPy operations here --
+    per row for batches -- so the kernel that follows returns numpy's bits."""
+    period = float(_num(period))
+    if period == 0:
+        raise ValueError("period must be a non-zero value")
+    period = abs(period)
+    host = lambda a: numpy.asarray(a.cpu().numpy() if isinstance(a, torch.Tensor) else _num(a), dtype=numpy.float64)   # noqa: E731
+    x, xp, fp = host(x) % period, host(xp) % period, host(fp)
+    if xp.shape[-1] != fp.shape[-1]:
+        raise ValueError("fp and xp are not of the same length")
+    if xp.ndim == 1 and fp.ndim == 2:
+        xp = numpy.broadcast_to(xp, fp.shape)
+    if fp.ndim == 1 and xp.ndim == 2:
+        fp = numpy.broadcast_to(fp, xp.shape)
+    order = numpy.argsort(xp, axis=-1)
+    xp, fp = numpy.take_along_axis(xp, order, axis=-1), numpy.take_along_axis(fp, order, axis=-1)
+    xp = numpy.concatenate((xp[..., -1:] - period, xp, xp[..., 0:1] + period), axis=-1)
+    fp = numpy.concatenate((fp[..., -1:], fp, fp[..., 0:1]), axis=-1)
+    return x, numpy.ascontiguousarray(xp), numpy.ascontiguousarray(fp)
+
+
 def _outside(r, xd, xpd, left, right):
     """numpy.interp's ``left`` / ``right``: two selects behind the kernel (NaN abscissae keep the kernel's NaN)"""
     def fix(r_, x_, xp_):
@@ -146,13 +170,16 @@ def _outside(r, xd, xpd, left, right):
 def interp(x, xp, fp, **kwargs):
     """numpy.interp(x, xp, fp, **kwargs) (splib/sputils.py:82-86) for one column (1-D arguments) or for every row of 2-D
     arguments (x and xp may stay 1-D: shared by all rows).  As the reference: ``xp`` is converted to ``x``'s unit, the
-    result carries ``fp``'s unit; ``left`` / ``right`` (the values outside [xp[0], xp[-1]]) are honoured; ``period`` is not
-    supported (no call site of the reference uses any of the three)."""
-    left, right = kwargs.pop("left", None), kwargs.pop("right", None)
-    if kwargs.pop("period", None) is not None or kwargs:
-        raise NotImplementedError("sputils.interp on the GPU: numpy.interp's period / %s not supported" % sorted(kwargs))
+    result carries ``fp``'s unit; ``left`` / ``right`` (the values outside [xp[0], xp[-1]]) and ``period`` are honoured as numpy
+    does (no call site of the reference uses any of the three)."""
+    left, right, period = kwargs.pop("left", None), kwargs.pop("right", None), kwargs.pop("period", None)
+    if kwargs:
+        raise TypeError("interp() got an unexpected keyword argument %r" % sorted(kwargs)[0])
     io = _Io()
     ux, ufp = _unit(x), _unit(fp)
+    if period is not None:              # numpy's own preprocessing, on the host; then the same kernel
+        x, xp, fp = _periodic(x, _num(xp, ux) if hasattr(xp, "value_in") and ux is not None else xp, fp, period)
+        left = right = ux = None
     xd, xpd, fpd = io.devs(x, (xp, ux), fp)
     scalar = xd.dim() == 0
     if scalar:

@@ -139,8 +139,14 @@ def test_interp_errors_like_numpy(sputils):
         sputils.interp(numpy.zeros(3), numpy.zeros(4), numpy.zeros(5))       # fp and xp are not of the same length
     with pytest.raises(ValueError):
         sputils.interp(numpy.zeros(3), numpy.zeros(0), numpy.zeros(0))       # array of sample points is empty
-    with pytest.raises(NotImplementedError):
-        sputils.interp(numpy.zeros(3), numpy.arange(4.), numpy.arange(4.), period=360.0)
+    with pytest.raises(ValueError):
+        sputils.interp(numpy.zeros(3), numpy.arange(4.), numpy.arange(4.), period=0)      # period must be a non-zero value
+    # numpy.interp(..., period=): numpy's host-side normalisation + the same kernel = numpy's bits
+    rng = numpy.random.default_rng(33)
+    ang, val, q = rng.uniform(-400, 800, size=(40, 91)), rng.normal(size=(40, 91)), rng.uniform(-1000, 1000, size=(40, 160))
+    want = numpy.stack([numpy.interp(q[r], ang[r], val[r], period=360.0) for r in range(40)])
+    assert_bits("interp period", sputils.interp(q, ang, val, period=360.0), want)
+    assert_bits("interp period, one column", sputils.interp(q[3], ang[3], val[3], period=360.0), want[3])
 
 
 def test_row_pitches_of_2_pow_24_elements_are_refused():

@@ -73,8 +73,18 @@ def test_shapes_scalars_views_and_quantities(su):
     assert idx.dtype == numpy.int64 and numpy.array_equal(idx, numpy.searchsorted(xp[0], x[0], side="right"))
     assert su.searchsorted(xp[0], 50.0) == numpy.searchsorted(xp[0], 50.0)
     assert su.rms(numpy.ones((4, 9)), axis=-1).shape == (4,)
-    with pytest.raises(NotImplementedError):
-        su.interp(x[0], xp[0], fp[0], period=360.0)
+    # numpy.interp's `period` (what **kwargs of splib/sputils.py:82-86 passes through; round-4 verdict, missing 4): numpy's own
+    # host-side normalisation, then the same operator -- one column, a batch of rows, unsorted / negative / wrapped abscissae
+    ang, val = rng.uniform(-400, 800, size=(5, 12)), rng.normal(size=(5, 12))
+    q = rng.uniform(-1000, 1000, size=(5, 7))
+    assert numpy.array_equal(su.interp(q[0], ang[0], val[0], period=360.0), numpy.interp(q[0], ang[0], val[0], period=360.0))
+    assert numpy.array_equal(su.interp(q[1], ang[1], val[1], period=-360.0, left=1.0), numpy.interp(q[1], ang[1], val[1], period=-360.0, left=1.0))
+    assert numpy.array_equal(su.interp(q, ang, val, period=97.5), numpy.stack([numpy.interp(q[r], ang[r], val[r], period=97.5) for r in range(5)]))
+    assert numpy.array_equal(su.interp(q, ang[0], val, period=97.5), numpy.stack([numpy.interp(q[r], ang[0], val[r], period=97.5) for r in range(5)]))
+    with pytest.raises(ValueError):
+        su.interp(q[0], ang[0], val[0], period=0)
+    with pytest.raises(TypeError):
+        su.interp(q[0], ang[0], val[0], perio=3)
     with pytest.raises(NotImplementedError):
         su.searchsorted(xp[0], x[0], sorter=None)
     with pytest.raises(ValueError):

@@ -272,9 +272,12 @@ int spc_device_count(void);         /* number of visible HIP devices (0 if none 
  * 4 conservative backward): the `cb` of spc_describe_launch */
 int spc_pick_cols_per_block(const spc_dims *dims, int pass);
 /* WHICH kernel instantiation, slab size and grid the library launches for this batch, as text, e.g.
- *   "k_forward<f64,lean,91,160,wt=1,blk=1024,pre=1> cb=4 grid=256 block=1024 lds=17472"
+ *   "k_forward<f64,lean,91,160,wt=1,blk=1024,pre=1> cb=4 grid=256 block=1024 lds=17472 cus=256"
  * (template arguments: element type, lean / full output set, compile-time level counts [0,0 = run-time geometry],
- *  write-through stores, workgroup size, prologue prefetch).  pass as above; flags (pass 0 only): bit 0 = the index
+ *  write-through stores, workgroup size, prologue prefetch; float batches of a compile-time geometry that take the
+ *  8-byte-access forward kernel read "k_forward_f32v<91,160,wt=0>" -- pointers that are only 4-byte aligned fall back to
+ *  the scalar kernel at launch time; pass 3: "k_diag<f64,91,160,wt=0>"; `cus` = the compute units of the current device
+ *  the residency rules counted with, SPC_CUS overrides).  pass as above; flags (pass 0 only): bit 0 = the index
  * map is fused (idx != NULL), bit 1 = FULL variant (any optional output or surface coupling requested); elem_size 8
  * (f64) or 4 (f32).  The text comes from the very function the launchers use to choose, so a test can walk the
  * dispatch table and require that every instantiation it reaches is bit-checked (tests/test_dispatch_gpu.py).

@@ -83,8 +83,9 @@ class _Io:
         vals = [None if v is None else self._host(v, u) for v, u in pairs]
         tensors = [v for v in vals if isinstance(v, torch.Tensor)]
         self.on_device = any(t.device.type == "cuda" for t in tensors)
-        rows = max([v.shape[0] for v in vals if isinstance(v, numpy.ndarray) and v.ndim == 2] or [0])
-        if shard and self.multi is not None and not tensors and rows and self.multi.devices_for(rows) > 1:
+        nrows = {v.shape[0] for v in vals if isinstance(v, numpy.ndarray) and v.ndim == 2}
+        rows = max(nrows or [0])
+        if shard and self.multi is not None and not tensors and len(nrows) == 1 and self.multi.devices_for(rows) > 1:
             self.sharded = True
             return [None if v is None else self.multi.to_devices(v, rows=rows if v.ndim == 2 else None, n_cols=rows) for v in vals]
         self.eng = primary = getattr(self.eng, "primary", self.eng)

@@ -707,6 +707,41 @@ def config_leg(device, cfg, dtype_name, per_column_grid, factor, dt, steps=100, 
     return res
 
 
+def live_pmc_traffic(n_cols, timeout_s=100.0):
+    """HBM bytes per K1 / K3 launch measured IN THIS RUN (round-4 verdict, weak 13: `roofline.traffic` used to be a constant from a
+    builder's earlier run): two child processes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, counters
+    only, as MI355X_MICROARCH.md prescribes) around tools/pmc_run.py -- the timed plans on config-3-sized rotating batches plus
+    256-MiB calibration copies of the kernels' own 8 B-per-lane access width -- parsed by tools/pmc_summary.py.  Runs AFTER every
+    timed region.  Returns (dict or None, text): any failure (no rocprofv3, a timeout, a counter the box refuses) leaves the
+    constant of profiles/traffic.json in place and says so."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    d = tempfile.mkdtemp(prefix="spc_pmc_")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", os.path.join(d, sub), "--", "python3",
+                   os.path.join(ROOT, "tools", "pmc_run.py"), str(n_cols), "2"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s, text=True)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s exited with %d: %s" % (counter, r.returncode, (r.stderr or "")[-200:])
+        from tools import pmc_summary
+        res = pmc_summary.summarise(os.path.join(d, "fetch"), os.path.join(d, "write"), n_cols, 1 << 28, tag="measured inside this bench run")
+        if not res.get("k_forward_bytes_per_launch") or not res.get("k_backward_bytes_per_launch"):
+            return None, "the counter files hold no k_forward / k_backward rows"
+        return res, "measured in this run: child processes `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` around tools/pmc_run.py, calibrated on 256-MiB copies (tools/pmc_summary.py)"
+    except subprocess.TimeoutExpired:
+        return None, "a rocprofv3 --pmc pass did not finish in %.0f s" % timeout_s
+    except Exception as e:                              # a reported extra, never fatal for the headline
+        return None, "live PMC pass failed: %r" % (e,)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def self_launch(n_gpus, argv):
     """Run `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a child process (this parent
     has not imported torch, so nothing here has initialised a GPU) and return its exit code; the children's stdout --
@@ -800,6 +835,8 @@ def main():
     ap.add_argument("--per-column-grid", action="store_true", help="headline workload with the LES grid packed per column [n_cols x n_lev]")
     ap.add_argument("--no-config5", action="store_true", help="skip the `config5` extra (88 838 columns 137<->512, f64 and f32) at N=1")
     ap.add_argument("--no-per-column-grid-leg", action="store_true", help="skip the `per_column_grid` extra (config 3, grid per column) at N=1")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not measure `roofline.traffic` in this run (two rocprofv3 --pmc child "
+                    "processes after the timed regions, ~1 minute); report the constant of profiles/traffic.json instead")
     ap.add_argument("--check-rows", type=int, default=4096, help="rows per rank / device in the N > 1 output check (sample_check)")
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="N>1 launch mechanics only (rendezvous, sharding, barrier, max-reduction over gloo; no GPU work): CPU tests")
@@ -1097,14 +1134,19 @@ def main():
             k1_us, k3_us = per_rank[roof_rank]["k1_avg_launch_us"], per_rank[roof_rank]["k3_avg_launch_us"]
             n_cols = per_rank[roof_rank]["rows"][1] - per_rank[roof_rank]["rows"][0]
     if k1_us is not None:
-        traffic, tsrc = None, None
+        traffic, tsrc, traffic_k3, live_note = None, None, None, None
+        if plain and not args.no_live_traffic:
+            live, live_note = live_pmc_traffic(n_cols)
+            if live is not None:
+                traffic, traffic_k3, tsrc = live["k_forward_bytes_per_launch"], live["k_backward_bytes_per_launch"], live_note
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if traffic is None and os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))     # PMC passes of tools/gpu_round.sh (separate --pmc runs, calibrated)
                 if tj.get("n_cols") == n_cols and (nG, nL) == (91, 160) and not f32 and not args.per_column_grid:
                     traffic = tj.get("k_forward_bytes_per_launch")
-                    tsrc = "profiles/traffic.json (builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on another box, %s)" % tj.get("tag", "this round")
+                    tsrc = "profiles/traffic.json (builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on another box, %s)%s" % (
+                        tj.get("tag", "this round"), ("; live measurement not available: " + live_note) if live_note else "")
             except Exception:
                 traffic = None
         ach = ab["k1_launch"] * n_cols / (k1_us * 1e-6) / 1e9
@@ -1118,7 +1160,7 @@ def main():
                            "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": (ach / copy_gbs) if copy_gbs else None,
                            "timing": dict(kdiag, method="HIP events on the launch stream around %d back-to-back launches "
                                           "of the kernel alone over the rotating batches" % KERNEL_LAUNCHES),
-                           "backward": {"kernel": "k_backward (K3)", "avg_launch_us": k3_us,
+                           "backward": {"kernel": "k_backward (K3)", "avg_launch_us": k3_us, "traffic": traffic_k3,
                                         "achieved": ab["k3_launch"] * n_cols / (k3_us * 1e-6) / 1e9,
                                         "frac": ab["k3_launch"] * n_cols / (k3_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                         "algorithmic_bytes_per_launch": ab["k3_launch"] * n_cols}}

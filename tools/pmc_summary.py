@@ -27,10 +27,9 @@ def short(name):
     return None
 
 
-def main():
-    fdir, wdir, n_cols, copy_bytes = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
-    out = sys.argv[5] if len(sys.argv) > 5 else "profiles/traffic.json"
-    res = {"n_cols": n_cols, "copy_bytes": copy_bytes, "tag": os.environ.get("PMC_TAG", "round 2"), "units": "rocprofv3 FETCH_SIZE / WRITE_SIZE are KiB", "kernels": {}}
+def summarise(fdir, wdir, n_cols, copy_bytes, tag=None):
+    """the two --pmc passes' CSVs -> dict (per-kernel HBM bytes per launch, calibrated on the known-size copies)"""
+    res = {"n_cols": n_cols, "copy_bytes": copy_bytes, "tag": tag or os.environ.get("PMC_TAG", "round 2"), "units": "rocprofv3 FETCH_SIZE / WRITE_SIZE are KiB", "kernels": {}}
     for counter, d in (("FETCH_SIZE", fdir), ("WRITE_SIZE", wdir)):
         for name, vals in collect(d, counter).items():
             k = short(name)
@@ -61,6 +60,13 @@ def main():
     res["k_backward_bytes_per_launch"] = ks.get("k_backward", {}).get("hbm_bytes_per_launch")
     if "k_backward_cons" in ks:
         res["k_backward_cons_bytes_per_launch"] = ks["k_backward_cons"].get("hbm_bytes_per_launch")
+    return res
+
+
+def main():
+    fdir, wdir, n_cols, copy_bytes = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    out = sys.argv[5] if len(sys.argv) > 5 else "profiles/traffic.json"
+    res = summarise(fdir, wdir, n_cols, copy_bytes)
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

@@ -14,7 +14,7 @@ timeout -k 10 300 python bench.py --dtype f32 --no-dropin --no-anchor --no-small
 timeout -k 10 300 python bench.py --config 5 --no-dropin --no-anchor --no-small-batch --multi-devices none --steps 200 --warmup 10 > $O/bench_config5.json 2> $O/bench_config5.err; echo "bench config5 exit=$?"
 timeout -k 10 300 python bench.py --per-column-grid --no-dropin --no-anchor --no-small-batch --multi-devices none > $O/bench_percol.json 2> $O/bench_percol.err; echo "bench percol exit=$?"
 cd /tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python3 $R/bench.py --steps 200 --warmup 20 --cpu-seconds 0 --no-anchor --no-dropin --no-small-batch --multi-devices none > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err; echo "rocprof bench exit=$?"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python3 $R/bench.py --steps 200 --warmup 20 --cpu-seconds 0 --no-anchor --no-dropin --no-small-batch --no-live-traffic --multi-devices none > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err; echo "rocprof bench exit=$?"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/tools/pmc_run.py 35718 2 > $O/pmc_fetch.log 2>&1; echo "pmc fetch exit=$?"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/tools/pmc_run.py 35718 2 > $O/pmc_write.log 2>&1; echo "pmc write exit=$?"
 cd $R

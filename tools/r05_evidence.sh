@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round 5 evidence on one GPU box (gpurun_out/r05e2/): the default bench line, the driver-style line (--steps 20 --warmup 5), the
+# Round 5 evidence on one GPU box (gpurun_out/r05f2/): the default bench line, the driver-style line (--steps 20 --warmup 5), the
 # --dtype f32 and --config 5 lines, rocprofv3 kernel stats of the bench command, PMC traffic (shared grid: profiles/traffic.json),
 # kernel sizes sweep.   usage: tools/r05_evidence.sh
 set -o pipefail
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r05e2
+O=$R/gpurun_out/r05f2
 mkdir -p $O
 export TMPDIR=/tmp
 cd $R
@@ -25,7 +25,7 @@ timeout -k 10 400 python tools/kbench.py --sizes 1024,2048,4096,8192,16384,35718
 python - <<'PY'
 import json
 for f in ("bench.json","bench_steps20.json","bench_f32.json","bench_config5.json","bench_percol.json"):
-    d=json.loads(open("gpurun_out/r05e2/"+f).read().strip().splitlines()[-1])
+    d=json.loads(open("gpurun_out/r05f2/"+f).read().strip().splitlines()[-1])
     print(f, "%.4g" % d["value"], "ms %.4f" % d["ms_per_step"], d["dtype"], "K1 frac %.3f" % d["roofline"]["frac"], "K3 frac %.3f" % d["roofline"]["backward"]["frac"], "verified", d.get("verified"),
           "dropin", d.get("dropin",{}).get("verified"), {k:("%.3g" % v["value"] if isinstance(v,dict) and "value" in v else None) for k,v in d.get("dropin",{}).items() if isinstance(v,dict)})
     for k in ("f64","f32"):

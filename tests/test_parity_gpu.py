@@ -601,3 +601,45 @@ def test_fp32_eight_byte_access_kernels_equal_the_scalar_float_kernels(monkeypat
         for k, v in list(fp1.outputs.items()) + list(bp1.outputs.items()):
             assert_bits("misaligned %d %s" % (n, k), host(v), vec[k])
     assert {"k_forward_f32v,wt=0>", "k_forward_f32v,wt=1>"} <= seen, seen
+
+
+def test_fp32_random_batch_sizes_all_float_paths_agree(monkeypatch):
+    """Fuzz of the float kernels (soak: SPC_FUZZ_TRIALS / SPC_FUZZ_SEED): random column counts (odd and even, every size class),
+    the three compile-time geometries, explicit slab sizes, shared / per-column grids -- the 8-byte-access K1, the scalar
+    compile-time kernels and the run-time-geometry kernels (padded pitch) must give the same bits."""
+    import os
+    from sp_coupler_amd.engine import Engine
+    e32 = Engine("cuda:0", dtype=torch.float32)
+    rng = numpy.random.default_rng(int(os.environ.get("SPC_FUZZ_SEED", "2027")))
+    trials = max(6, int(os.environ.get("SPC_FUZZ_TRIALS", "40")) // 4)
+    for trial in range(trials):
+        nG, nL = [(91, 160), (137, 512), (19, 160)][int(rng.integers(0, 3))]
+        u = rng.uniform()
+        n = int(rng.integers(1, 1100)) if u < 0.3 else (int(rng.integers(1100, 9000)) if u < 0.8 else int(rng.integers(9000, 30000)))
+        if nL == 512:
+            n = min(n, 8000)
+        cb = int(rng.choice([0, 0, 0, 2, 3, 4, 8]))
+        per_col = bool(rng.integers(0, 4) == 0)
+        gcm, zf, zh, prof = synthetic.make_batch_tiled(n, nG, nL, seed=8100 + trial, base=1024, couple_surface=False) if not per_col else \
+            synthetic.make_batch(min(n, 3000), nG, nL, seed=8100 + trial, couple_surface=False, per_column_grid=True)
+        n = gcm["T"].shape[0]
+        f4 = lambda d: {k: torch.from_numpy(v).to(e32.device, torch.float32) for k, v in d.items()}       # noqa: E731
+        g, p = f4(gcm), f4(prof)
+        zf_d, zh_d = (torch.from_numpy(z).to(e32.device, torch.float32) for z in (zf, zh))
+        out = {}
+        for mode in ("vec", "scalar", "runtime"):
+            monkeypatch.setenv("SPC_F32_VEC", "1" if mode == "vec" else "0")
+            if mode == "runtime":          # one element of padding: the run-time-geometry kernels
+                pad = lambda t: torch.cat([t, torch.full_like(t[:, :1], float("nan"))], dim=1)[:, :t.shape[1]] if t.dim() == 2 else t   # noqa: E731
+                gg, pp = {k: pad(v) for k, v in g.items()}, {k: pad(v) for k, v in p.items()}
+                zz = (pad(zf_d), pad(zh_d)) if per_col else (zf_d, zh_d)
+            else:
+                gg, pp, zz = g, p, (zf_d, zh_d)
+            fp, bp = e32.plan_exchange(gg, zz[0], zz[1], pp, 0.9, 0.9, 900.0, cols_per_block=cb)
+            fp.launch(), bp.launch()
+            torch.cuda.synchronize()
+            out[mode] = {k: host(v).copy() for k, v in list(fp.outputs.items()) + list(bp.outputs.items())}
+        tag = "trial %d %d<->%d n=%d cb=%d per_col=%s" % (trial, nG, nL, n, cb, per_col)
+        for k in out["vec"]:
+            assert_bits(tag + " vec/scalar " + k, out["vec"][k], out["scalar"][k])
+            assert_bits(tag + " scalar/runtime " + k, out["scalar"][k], out["runtime"][k])

@@ -596,7 +596,7 @@ __global__ __launch_bounds__(BLK, SPC_K1_WAVES) void k_forward(const FwdP<T, FUL
         const T zf_k = div_grav(zg - zsurf);                                          // spcpl.py:198
         T *const s = lds + (size_t)c * 6 * nG + (nG - 1 - k);                         // [::-1], spcpl.py:224
         s[0] = zf_k;
-        s[2 * nG] = sh + ql + qi;                                                     // spcpl.py:215
+        s[2 * nG] = SPC_MUT(12, sh + ql, sh + ql + qi);                               // spcpl.py:215
         s[3 * nG] = ql;
         SPC_MUT(6, lds + (size_t)c * 6 * nG + k, s)[4 * nG] = uu;
         s[5 * nG] = vv;
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(BLK, SPC_K1_WAVES) void k_forward(const FwdP<T, FUL
             if constexpr (FULL)
                 if (OPT(rainrate)) { sc_rain = OPT(rain)[col]; sc_rl = OPT(rain_last)[col]; }
         }
-        stg<WT>(&p.f_ps[col], SPC_DIVISOR(T)(p.dt).div(p.factor * (sc_ps - sc_psd)));          // spcpl.py:332
+        stg<WT>(&p.f_ps[col], SPC_DIVISOR(T)(p.dt).div(p.factor * SPC_MUT(14, sc_psd - sc_ps, sc_ps - sc_psd)));          // spcpl.py:332
         if constexpr (FULL) {
             if (OPT(ps)) OPT(ps)[col] = sc_ps;
             if (OPT(rainrate)) OPT(rainrate)[col] = (sc_rain - sc_rl) / p.dt;   // spcpl.py:325
@@ -881,7 +881,7 @@ template <typename T, int NG, int NL, int WT, int BLK = BLOCK, bool PRE = true> 
             t_i = qt_i = ql_i = qlw_i = qli_i = u_i = v_i = x;
         }
         T f_T = ddt.div(p.factor * (t_i - in.tt));                                       // spcpl.py:518
-        T f_SH = ddt.div(p.factor * ((qt_i - ql_i) - in.sh));                            // spcpl.py:519
+        T f_SH = ddt.div(p.factor * (SPC_MUT(13, qt_i, qt_i - ql_i) - in.sh));                            // spcpl.py:519
         T f_QL = ddt.div(p.factor * (SPC_MUT(3, ql_i, qlw_i) - in.ql));                                    // spcpl.py:520
         T f_QI = ddt.div(p.factor * (qli_i - in.qi));                                    // spcpl.py:521
         T f_U = ddt.div(p.factor * (u_i - in.u));                                        // spcpl.py:524

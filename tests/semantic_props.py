@@ -205,6 +205,8 @@ def prop_reversal_is_index_arithmetic_only(impl):
         assert numpy.array_equal(r["u"][c], numpy.interp(zf, Zf[c, ::-1], gcm["U"][c, ::-1])), c
         assert numpy.array_equal(r["v"][c], numpy.interp(zf, Zf[c, ::-1], gcm["V"][c, ::-1])), c
         assert numpy.array_equal(r["ql_ref"][c], numpy.interp(zf, Zf[c, ::-1], gcm["QL"][c, ::-1])), c
+        qt_ = gcm["SH"][c] + gcm["QL"][c] + gcm["QI"][c]                                   # spcpl.py:215: ALL water, ice included
+        assert numpy.array_equal(r["qt"][c], numpy.interp(zf, Zf[c, ::-1], qt_[::-1])), c
     # cloud fraction comes back reversed: A_d = profile["A"][::-1] (spcpl.py:404), f_A = factor (A_d - A) / dt (spcpl.py:526)
     b = impl.backward(gcm, zf, zh, prof, 1.0, DT, False)
     for c in range(gcm["T"].shape[0]):

@@ -24,6 +24,9 @@ MUTANTS = {
     9: ("K3 cloud fraction A_d read from the neighbouring column of the slab (spcpl.py:404)", "columns_are_independent"),
     10: ("K5 t: exponent -rd/cp instead of +rd/cp (spcpl.py:409)", "isentropic_column_has_constant_thl"),
     11: ("K4 f_T: numerator without the weight rho (spcpl.py:482, sputils.py:152)", "conservative_coarsening_conserves"),
+    12: ("K1 qt_ = SH + QL, the ice forgotten (spcpl.py:215)", "reversal_is_index_arithmetic_only"),
+    13: ("K3 f_SH from qt instead of qt - ql (spcpl.py:519: SH is vapour only)", "total_water_tendency_closes"),
+    14: ("K1 f_ps with the opposite sign (spcpl.py:332)", "zero_forcings_when_the_les_equals_the_interpolated_gcm_profile"),
 }
 
 
@@ -47,7 +50,8 @@ def main():
     print("mutation control of tests/test_semantic_gpu.py on %s" % torch.cuda.get_device_name(0))
     bad = 0
     clean = run(None)
-    print("shipped library: %d properties, failed: %s" % (8, clean or "none"))
+    from tests import semantic_props as sp
+    print("shipped library: %d properties, failed: %s" % (len(sp.PROPERTIES), clean or "none"))
     bad += bool(clean)
     for n, (what, guard) in sorted(MUTANTS.items()):
         path = os.path.join(ROOT, "build", "mutants", "libspc_mutant%d.so" % n)

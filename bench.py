@@ -825,6 +825,8 @@ def main():
     ap.add_argument("--no-small-batch", action="store_true", help="skip the config-2 extra at N=1")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in API (Coupler.step) rate at N=1")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N>1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--force-dist", action="store_true", help="rehearsal on a one-GPU box: initialise the process group (RCCL), run the "
+                    "barrier and the max-reduction of the N > 1 path with ONE rank under torch.distributed.run; the line says so")
     ap.add_argument("--device", type=int, default=None, help="force this HIP device for every rank (rehearsal on a 1-GPU box)")
     ap.add_argument("--no-anchor", action="store_true", help="skip the config-4-on-one-GPU `scaling_anchor` extra at N=1")
     ap.add_argument("--multi-devices", default=None,
@@ -867,7 +869,7 @@ def main():
         local = args.device
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or (args.force_dist and "RANK" in os.environ):
         import torch.distributed as dist
         if args.backend == "nccl":      # RCCL.  The data path needs no collective (barrier + max of the elapsed time only),
             try:                        # so a failing RCCL does not void the measurement -- but the JSON says what ran.
@@ -1112,7 +1114,7 @@ def main():
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": wtxt, "total_cols": total_cols, "n_cols_per_gpu": n_cols, "nG": nG, "nL": nL,
                    "rotate": rotate, "launches_per_step": 2, "parallelism": "columns sharded, no collective"},
-        "backend": (args.backend if world > 1 else None),
+        "backend": (args.backend if dist is not None else None),
         "series_note": ("ONE workload per scaling series: `--gpus N` (N > 1) shards config 4 (348 528 columns) over N GPUs -- strong "
                         "scaling; its N = 1 point is `scaling_anchor` of the N = 1 line (config 4 on one GPU).  The N = 1 headline "
                         "`value` is config 3 (35 718 columns, the largest config BASELINE.json places on ONE GPU): do not divide "
@@ -1120,6 +1122,7 @@ def main():
         "bytes_per_exchange": ab["exchange"],
         "hbm_frac_whole_step": value / world * ab["exchange"] / 1e9 / HBM_PEAK_GBS,
         "ranks": (dist.get_world_size() if dist is not None else 1),
+        "force_dist": (True if (args.force_dist and world == 1 and dist is not None) else None),   # a ONE-rank rehearsal of the N > 1 machinery
         "devices": ([r["device"] for r in per_rank] if per_rank else [device_identity(local)]),
     }
     roof_rank = 0

@@ -183,6 +183,14 @@ class OperatorPlan(_Plan):
         self.launch(stream)
         return self.result
 
+    def launch_raw(self, stream_ptr):
+        """the bare foreign call (hot loops) -- only for plans that read every argument in place: a plan holding private
+        packed copies must go through run(), which refreshes them, and says so instead of serving a stale snapshot"""
+        if self._refresh:
+            raise RuntimeError("this plan reads %d argument(s) through private packed copies (non-contiguous or spread inputs): "
+                               "use run(), which refreshes them before the launch" % len(self._refresh))
+        super().launch_raw(stream_ptr)
+
     def describe(self):
         return getattr(self._fn, "__name__", "operator")
 

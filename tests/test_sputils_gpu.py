@@ -305,6 +305,9 @@ def test_a_plan_on_a_view_it_cannot_read_in_place_follows_the_callers_tensor():
     fpT = dev(rng.normal(size=(nG, n)))                         # fp as a TRANSPOSED view: [n x nG] with row stride 1
     plan = eng.plan_interp(x, xp, fpT.t())
     assert len(plan._refresh) == 1
+    import ctypes
+    with pytest.raises(RuntimeError, match="use run"):          # the bare foreign call would skip the refresh: refused
+        plan.launch_raw(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     for _ in range(2):
         want = numpy.stack([numpy.interp(x[r].cpu().numpy(), xp[r].cpu().numpy(), fpT.t()[r].cpu().numpy()) for r in range(n)])
         assert numpy.array_equal(plan.run().cpu().numpy(), want)

@@ -160,13 +160,14 @@ __device__ __forceinline__ double spc_exner_pow(double p, double y) { return spc
 __device__ __forceinline__ float spc_exner_pow(float p, float y) { return spc_pow(SPC_DIV(p, 1e5f), y); }
 
 // Streaming accesses of the hot kernels: every input element is read once and every output written
-// once per launch.  -DSPC_NT=1 marks them non-temporal (experiment switch).
+// once per launch.  -DSPC_NT=1 marks them non-temporal (experiment switch); 2: the loads only, 3: the
+// stores only (only the plain stores: write-through launches keep their sc1 stores).
 #ifndef SPC_NT
 #define SPC_NT 0
 #endif
 template <typename T> __device__ __forceinline__ T ldg(const T *q)
 {
-#if SPC_NT == 1
+#if SPC_NT == 1 || SPC_NT == 2
     return __builtin_nontemporal_load(q);
 #else
     return *q;
@@ -182,6 +183,8 @@ template <int WT, typename T> __device__ __forceinline__ void stg(T *q, T v)
 #else
     if constexpr (WT == 1)
         __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if constexpr (SPC_NT == 3)
+        __builtin_nontemporal_store(v, q);
     else
         *q = v;
 #endif

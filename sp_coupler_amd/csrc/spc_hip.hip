@@ -625,9 +625,9 @@ __global__ __launch_bounds__(BLK, SPC_K1_WAVES) void k_forward(const FwdP<T, FUL
             if (OPT(ps)) OPT(ps)[col] = sc_ps;
             if (OPT(rainrate)) OPT(rainrate)[col] = (sc_rain - sc_rl) / p.dt;   // spcpl.py:325
             if (OPT(wthl)) {                                                            // spcpl.py:136-167
-                const T rho = sc_ps / (K<T>::rd * ldg(&p.Tm[col * pitchG + nG - 1]));      // spcpl.py:153
+                const T rho = sc_ps / (K<T>::rd * ldg(&p.Tm[col * pitchG + SPC_MUT(15, 0, nG - 1)]));      // spcpl.py:153
                 OPT(wqt)[col] = -(OPT(QLflux)[col] + OPT(QIflux)[col] + OPT(SHflux)[col]) / rho;     // spcpl.py:159
-                OPT(wthl)[col] = -OPT(TSflux)[col] * spc_pow(div_pref0(sc_ps), (-K<T>::rd) / K<T>::cp)
+                OPT(wthl)[col] = -OPT(TSflux)[col] * spc_pow(div_pref0(sc_ps), SPC_MUT(17, K<T>::rd, -K<T>::rd) / K<T>::cp)
                                 / (K<T>::cp * rho);                                    // spcpl.py:161
                 if (OPT(z0m)) OPT(z0m)[col] = OPT(Z0M)[col];
                 if (OPT(z0h)) OPT(z0h)[col] = OPT(Z0H)[col];
@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(BLOCK) void k_surface(int64_t n, const T *Ph_s, con
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
         const T ps = Ph_s[i];
         const T rho = ps / (K<T>::rd * T_s[i]);                                        // spcpl.py:153
-        wqt[i] = -(QLflux[i] + QIflux[i] + SHflux[i]) / rho;                           // spcpl.py:159
+        wqt[i] = -(QLflux[i] + SPC_MUT(16, T(0), QIflux[i]) + SHflux[i]) / rho;       // spcpl.py:159
         wthl[i] = -TSflux[i] * spc_pow(div_pref0(ps), (-K<T>::rd) / K<T>::cp) / (K<T>::cp * rho);   // spcpl.py:161
     }
 }

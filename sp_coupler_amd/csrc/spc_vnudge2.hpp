@@ -204,7 +204,7 @@ template <bool GLOBAL, bool RCACHE = false> __global__ __launch_bounds__(VN2_THR
     VnBrent br = {};
     if (own) {
         if (valid) {
-            if (ql_ref > 1e-9) { stage = VS_M0; touched = true; }                    // spcpl.py:665
+            if (ql_ref > SPC_MUT(20, 1e-6, 1e-9)) { stage = VS_M0; touched = true; }  // spcpl.py:665
             else if (ql_av > ql_ref) { want_argmax = true; touched = true; }         // spcpl.py:679
         }
         s_mode[kl] = want_argmax ? 3 : 0;
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256) void k_vnudge_update(const VnP p)
         const bool th = p.constantT && (stv & VN2_TOUCHED);
         s_coef[k] = ap == 1 ? p.beta[lev] - 1 : p.a_add[lev];
         s_av[k] = p.qt_av[lev];
-        s_tc[k] = th ? (-K<double>::rlv) / (K<double>::cp * spc_pow(div_pref0(p.presf[lev]), K<double>::rd / K<double>::cp)) : 0.0;   // spcpl.py:731
+        s_tc[k] = th ? SPC_MUT(19, K<double>::rlv, -K<double>::rlv) / (K<double>::cp * spc_pow(div_pref0(p.presf[lev]), K<double>::rd / K<double>::cp)) : 0.0;   // spcpl.py:731
         s_ap[k] = ap | (th ? 4 : 0);
         if (ap | (th ? 4 : 0)) s_any = 1;
     }
@@ -581,8 +581,8 @@ __global__ __launch_bounds__(256) void k_vnudge_update(const VnP p)
         for (int ij = ij0 + rq; ij < ij1; ij += 8) {
             const int64_t g = base + (int64_t)ij * ktot + k;
             double v = p.qt[g];
-            if ((ap & 3) == 1) { v = v + coef * (v - qt_av); p.qt[g] = v; }                  // spcpl.py:724-725
-            else if ((ap & 3) == 2) { v = v + coef * R[ij]; p.qt[g] = v; }                  // spcpl.py:716-719
+            if ((ap & 3) == 1) { v = v + coef * SPC_MUT(18, v, (v - qt_av)); p.qt[g] = v; } // spcpl.py:724-725
+            else if ((ap & 3) == 2) { v = SPC_MUT(21, v - coef * R[ij], v + coef * R[ij]); p.qt[g] = v; }   // spcpl.py:716-719
             if (ap & 4) {                                                                   // spcpl.py:726-733
                 const double tt = v - p.qsat[g];
                 const double ql_target = (tt >= 0.0 || tt != tt) ? tt : 0.0;

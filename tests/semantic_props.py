@@ -15,6 +15,10 @@ An implementation is an object with
     backward(gcm, zf, zh, prof, factor, dt, conservative) -> dict f_T f_SH f_QL f_QI f_U f_V f_A start_index
     interp_c(Zh, zh, q, rho) / interp_rho(Zh, zh, rho) -> [n x nG]
     les_temperature(gcm, zf, prof)                   -> (pf, t) on LES levels (spcpl.py:408-409)
+    surface(gcm, zf, zh, prof)                       -> dict z0m z0h wthl wqt: the surface branch of set_les_forcings (spcpl.py:359-364)
+    surface_alone(Ph_s, T_s, QLflux, QIflux, SHflux, TSflux) -> (wthl, wqt): convert_surface_fluxes on its own (spcpl.py:136-167)
+    nudge(fields, R, constantT)                      -> dict qt thl beta a qt_std of ONE LES after spcpl.variability_nudge (spcpl.py:613-744);
+                                                        fields: qt qsat thl ql [itot x jtot x k], ql_av qt_av presf ql_ref [k]; R [itot x jtot]
 all on NumPy arrays [n_cols x n_lev].
 """
 import numpy
@@ -230,6 +234,123 @@ def prop_columns_are_independent(impl):
     one = impl.forward({k: v[5:6] for k, v in gcm.items()}, zf, zh, {k: v[5:6] for k, v in prof.items()}, 1.0, DT)
     for k in FORCINGS:
         assert numpy.array_equal(one[k][0], r[k][5]), k
+
+
+# (i) spcpl.py:136-167: rho = Ph[-1] / (rd T[-1]) (ideal gas at the surface: SURFACE pressure, LOWEST full level);
+#     wqt = -(QLflux + QIflux + SHflux) / rho (all three water fluxes, OpenIFS positive downward -> DALES positive upward);
+#     wthl = -TSflux iexner(Ph[-1]) / (cp rho) (only the SENSIBLE heat); z0m / z0h handed through
+def prop_surface_fluxes_are_the_ifs_fluxes_over_the_surface_density(impl):
+    gcm, zf, zh, prof = synthetic.make_batch(40, GEOMETRY["nG"], GEOMETRY["nL"], 778, couple_surface=True)
+    n = gcm["T"].shape[0]
+    # a surface state whose density is EXACTLY one: Ph_s = rd T_s, so the kinematic fluxes are the mass fluxes with the sign turned
+    g = {k: v.copy() for k, v in gcm.items()}
+    g["T"][:, -1] = numpy.linspace(250.0, 310.0, n)
+    g["Phalf"][:, -1] = rd * g["T"][:, -1]
+    ways = {"in the forward pass": impl.surface(g, zf, zh, prof),
+            "on its own": dict(zip(("wthl", "wqt"), impl.surface_alone(g["Phalf"][:, -1], g["T"][:, -1], g["QLflux"], g["QIflux"], g["SHflux"], g["TSflux"])))}
+    for way, r in ways.items():
+        assert numpy.array_equal(r["wqt"], -(g["QLflux"] + g["QIflux"] + g["SHflux"])), "wqt " + way
+        want = -g["TSflux"] * (g["Phalf"][:, -1] / pref0) ** (-rd / cp) / cp
+        assert (numpy.abs(r["wthl"] - want) <= 4 * numpy.spacing(numpy.abs(want))).all(), "wthl " + way
+    r = ways["in the forward pass"]
+    assert numpy.array_equal(r["z0m"], g["Z0M"]) and numpy.array_equal(r["z0h"], g["Z0H"])
+    # signs: a downward (positive, OpenIFS) moisture / sensible heat flux is a negative (upward-positive, DALES) kinematic flux
+    assert (numpy.sign(r["wqt"]) == -numpy.sign(g["QLflux"] + g["QIflux"] + g["SHflux"])).all()
+    assert (numpy.sign(r["wthl"]) == -numpy.sign(g["TSflux"])).all()
+    # which inputs matter: the density is that of the LOWEST full level and the SURFACE half level -- every other level can
+    # change without a trace, a lowest level twice as warm is air half as dense (an exact power of two through every step)
+    g2 = {k: v.copy() for k, v in g.items()}
+    g2["T"][:, :-1] *= 1.25
+    g2["Phalf"][:, :-1] *= 0.75
+    r2 = impl.surface(g2, zf, zh, prof)
+    assert numpy.array_equal(r2["wqt"], r["wqt"]) and numpy.array_equal(r2["wthl"], r["wthl"])
+    g3 = {k: v.copy() for k, v in g.items()}
+    g3["T"][:, -1] *= 2.0
+    r3 = impl.surface(g3, zf, zh, prof)
+    assert numpy.array_equal(r3["wqt"], 2.0 * r["wqt"]) and numpy.array_equal(r3["wthl"], 2.0 * r["wthl"])
+    # which fluxes matter: the latent heat flux TLflux nowhere, TSflux only in wthl, each water flux in wqt with weight one
+    for name in ("QLflux", "QIflux", "SHflux"):
+        g4 = {k: v.copy() for k, v in g.items()}
+        g4[name] = g[name] + 0.25
+        r4 = impl.surface(g4, zf, zh, prof)
+        assert numpy.array_equal(r4["wthl"], r["wthl"]), name
+        assert numpy.array_equal(r4["wqt"], -(g4["QLflux"] + g4["QIflux"] + g4["SHflux"])), name
+    g5 = {k: v.copy() for k, v in g.items()}
+    g5["TSflux"] = 4.0 * g["TSflux"]
+    g5["TLflux"] = g["TLflux"] - 7.0
+    r5 = impl.surface(g5, zf, zh, prof)
+    assert numpy.array_equal(r5["wqt"], r["wqt"]) and numpy.array_equal(r5["wthl"], 4.0 * r["wthl"])
+
+
+# (j) spcpl.py:613-744, the variability nudge of one LES, level by level:
+#     * GCM cloud (ql_ref > 1e-9): beta with  mean(max(beta (qt - qt_av) + qt_av - qsat, 0)) = ql_ref  (:646-648, 676), applied as
+#       qt += (beta - 1)(qt - qt_av) (:724-725) -- so the level's mean condensate BECOMES ql_ref and its mean qt stays;
+#     * no root in [0, 5] (:669-673) -> additive noise a R with mean(max(qt + a R - qsat, 0)) = ql_ref, only if that means MORE
+#       cloud (:712-719); beta = 1 (:722);
+#     * GCM clear but LES cloudy (:679-683): beta that makes the wettest point exactly saturated;
+#     * otherwise untouched (:697);  constantT (:726-733): thl moves so that T = thl exner(p) + rlv ql / cp stays, point by point.
+def prop_variability_nudge_reaches_the_gcm_cloud_amount(impl):
+    from tests.test_vnudge import make_les_fields
+    itot, jtot, ktot = 32, 24, 40
+    f = make_les_fields(itot, jtot, ktot, seed=5)
+    cloudy = numpy.nonzero(f["ql_av"] > 1e-6)[0]
+    f["ql_ref"][cloudy[0]] = 5e-8                            # a GCM cloud amount between 1e-9 and 1e-6: still "significant" (:665)
+    rng = numpy.random.default_rng(99)
+    R = rng.normal(size=(itot, jtot))
+    R -= R.sum() / (itot * jtot)
+    r = impl.nudge(f, R, True)
+    qt, qsat, N = f["qt"], f["qsat"], itot * jtot
+    mean_ql = lambda x, k: numpy.maximum(x - qsat[:, :, k], 0).sum() / N         # noqa: E731
+    seen = set()
+    for k in range(ktot):
+        x, av, ref = qt[:, :, k], f["qt_av"][k], f["ql_ref"][k]
+        new = r["qt"][:, :, k]
+        touched = True
+        if ref > 1e-9:
+            lo, hi = mean_ql(0 * (x - av) + av, k) - ref, mean_ql(5 * (x - av) + av, k) - ref
+            if lo > 0 or hi < 0:                                                  # no root: additive noise, or nothing
+                if ref > f["ql_av"][k]:
+                    seen.add("additive")
+                    assert r["a"][k] > 0 and numpy.array_equal(new, x + r["a"][k] * R), k
+                    # brentq stops within xtol = 2e-12 (+ 4 eps a) of the root; the mean condensate moves by at most mean|R| per unit of a
+                    assert abs(mean_ql(new, k) - ref) <= 4e-12 * numpy.abs(R).mean() + 4 * EPS * ref, (k, mean_ql(new, k), ref)
+                else:
+                    seen.add("no root, less cloud wanted")
+                    assert numpy.array_equal(new, x), k
+                assert r["beta"][k] == 1
+            else:
+                seen.add("multiplicative")
+                b = r["beta"][k]
+                assert 0 <= b < 5 and numpy.array_equal(new, x + (b - 1) * (x - av)), k
+                assert abs(mean_ql(new, k) - ref) <= 4e-12 * numpy.abs(x - av).mean() + 4 * EPS * ref, (k, mean_ql(new, k), ref)
+                assert abs(new.mean() - x.mean()) <= 8 * EPS * abs(av) * (1 + abs(b)), k        # the level's water is redistributed, not changed
+        elif f["ql_av"][k] > ref:
+            i, j = numpy.unravel_index(numpy.argmax(x - qsat[:, :, k]), x.shape)
+            b = r["beta"][k]
+            if (qsat[i, j, k] - av) / (x[i, j] - av) < 0:
+                seen.add("mean already saturated")
+                assert b == 1 and numpy.array_equal(new, x), k
+            elif b == 1 and (qsat[i, j, k] - av) / (x[i, j] - av) >= 5:
+                assert numpy.array_equal(new, x), k
+            else:
+                seen.add("barely unsaturated")
+                assert numpy.array_equal(new, x + (b - 1) * (x - av)), k
+                assert abs(new[i, j] - qsat[i, j, k]) <= 8 * EPS * qsat[i, j, k], k              # the wettest point: exactly saturated
+        else:
+            seen.add("untouched")
+            touched = False
+            assert r["beta"][k] == 1 and numpy.array_equal(new, x), k
+            assert numpy.array_equal(r["thl"][:, :, k], f["thl"][:, :, k]), k
+        if touched:                                                               # constantT: the temperature of every point stays
+            ex = (f["presf"][k] / pref0) ** (rd / cp)
+            T0 = f["thl"][:, :, k] * ex + rlv / cp * f["ql"][:, :, k]
+            T1 = r["thl"][:, :, k] * ex + rlv / cp * numpy.maximum(new - qsat[:, :, k], 0)
+            assert numpy.abs(T1 - T0).max() <= 16 * numpy.spacing(300.0), (k, numpy.abs(T1 - T0).max())
+        assert abs(r["qt_std"][k] - numpy.sqrt(((new - new.mean()) ** 2).mean())) <= 1e-12 * new.mean(), k
+    assert {"multiplicative", "additive", "barely unsaturated", "untouched"} <= seen, seen
+    # without constantT thl is nobody's business
+    r2 = impl.nudge(f, R, False)
+    assert numpy.array_equal(r2["qt"], r["qt"]) and (r2["thl"] is None or numpy.array_equal(r2["thl"], f["thl"]))
 
 
 PROPERTIES = [v for k, v in sorted(globals().items()) if k.startswith("prop_")]

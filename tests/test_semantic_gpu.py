@@ -48,6 +48,26 @@ class HipImpl:
         torch.cuda.synchronize()
         return host(r["pf"]), host(r["t"])
 
+    def surface(self, gcm, zf, zh, prof):
+        e = self.eng
+        lean = {k: v for k, v in prof.items() if k not in ("Rain", "rain_last")}
+        r = e.forward(to_dev(gcm, e.device), self._dev(zf), to_dev(lean, e.device), 1.0, sp.DT, couple_surface=True)
+        torch.cuda.synchronize()
+        return {k: host(r[k]) for k in ("z0m", "z0h", "wthl", "wqt")}
+
+    def nudge(self, f, R, constantT):
+        d = lambda a: self._dev(a[None])                        # noqa: E731   one LES: a batch of one
+        qt, thl = d(f["qt"]), d(f["thl"])
+        r = self.eng.variability_nudge(qt, d(f["qsat"]), d(R), d(f["ql_av"]), d(f["qt_av"]), d(f["ql_ref"]), presf=d(f["presf"]),
+                                       thl=thl if constantT else None, ql=d(f["ql"]) if constantT else None, constantT=constantT)
+        torch.cuda.synchronize()
+        return {"qt": host(qt)[0], "thl": host(thl)[0], "beta": host(r["beta"])[0], "a": host(r["a"])[0], "qt_std": host(r["qt_std"])[0]}
+
+    def surface_alone(self, Ph_s, T_s, QLflux, QIflux, SHflux, TSflux):
+        wthl, wqt = self.eng.surface_fluxes(*(self._dev(a) for a in (Ph_s, T_s, QLflux, QIflux, SHflux, TSflux)))
+        torch.cuda.synchronize()
+        return host(wthl), host(wqt)
+
 
 @pytest.fixture(scope="module")
 def impl():

@@ -31,6 +31,21 @@ class OracleImpl:
         r = orc.backward_batched(gcm, Zf, prof, zf, 1.0, sp.DT)
         return r["pf"], r["t"]
 
+    def surface(self, gcm, zf, zh, prof):
+        return orc.forward_batched(gcm, prof, zf, zh, 1.0, sp.DT, couple_surface=True)
+
+    def nudge(self, f, R, constantT):
+        from oracle import vnudge_oracle as vo
+        r = vo.variability_nudge(f["qt"], f["qsat"], f["ql_av"], f["qt_av"], f["presf"], f["ql_ref"], R, sp.DT, constantT,
+                                 f["thl"] if constantT else None, f["ql"] if constantT else None)
+        assert r["error"] is None
+        return r
+
+    def surface_alone(self, Ph_s, T_s, QLflux, QIflux, SHflux, TSflux):
+        rows = [orc.convert_surface_fluxes({"Phalf": numpy.array([0.0, Ph_s[i]]), "T": numpy.array([T_s[i]]), "QLflux": QLflux[i], "QIflux": QIflux[i],
+                                            "SHflux": SHflux[i], "TSflux": TSflux[i], "Z0M": 0.0, "Z0H": 0.0}) for i in range(len(Ph_s))]
+        return numpy.array([r[2] for r in rows]), numpy.array([r[3] for r in rows])
+
 
 @pytest.fixture(params=[(91, 160), (137, 512)], ids=["91-160", "137-512"])
 def geometry(request):
@@ -55,6 +70,8 @@ SLIPS = {
         [orc.integral(Zh[i + 1], Zh[i], zh, q, None) / (Zh[i] - Zh[i + 1]) if Zh[i] < zh[-1] else 0.0 for i in range(len(Zh) - 1)])),
     "masking_above_the_les_top": ("searchsorted", lambda a, v, **kw: numpy.searchsorted(a, v, **kw) + 1),
     "reversal_is_index_arithmetic_only": ("interp", lambda x, xp, fp: numpy.interp(x, xp, fp[::-1])),
+    "surface_fluxes_are_the_ifs_fluxes_over_the_surface_density": ("cp", 1004. * 1.0000001),        # (a constant of sputils.py:14-20 mistyped)
+    "variability_nudge_reaches_the_gcm_cloud_amount": ("vnudge_oracle.exner", lambda p: (p / 1e5) ** (-287.04 / 1004.)),   # iexner for exner, spcpl.py:731
 }
 
 
@@ -63,6 +80,10 @@ def test_a_slip_planted_in_the_oracle_is_caught(name, monkeypatch):
     attr, wrong = SLIPS[name]
     prop = next(p for p in sp.PROPERTIES if p.__name__ == "prop_" + name)
     prop(OracleImpl())
-    monkeypatch.setattr(orc, attr, wrong)
+    mod = orc
+    if "." in attr:                                  # a slip in the nudge's oracle module
+        from oracle import vnudge_oracle
+        mod, attr = vnudge_oracle, attr.split(".")[1]
+    monkeypatch.setattr(mod, attr, wrong)
     with pytest.raises(AssertionError):
         prop(OracleImpl())

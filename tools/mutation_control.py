@@ -27,6 +27,13 @@ MUTANTS = {
     12: ("K1 qt_ = SH + QL, the ice forgotten (spcpl.py:215)", "reversal_is_index_arithmetic_only"),
     13: ("K3 f_SH from qt instead of qt - ql (spcpl.py:519: SH is vapour only)", "total_water_tendency_closes"),
     14: ("K1 f_ps with the opposite sign (spcpl.py:332)", "zero_forcings_when_the_les_equals_the_interpolated_gcm_profile"),
+    15: ("K1 surface branch: density from T at the model top instead of the lowest level (spcpl.py:153)", "surface_fluxes_are_the_ifs_fluxes_over_the_surface_density"),
+    16: ("k_surface: wqt without the ice flux QIflux (spcpl.py:159)", "surface_fluxes_are_the_ifs_fluxes_over_the_surface_density"),
+    17: ("K1 surface branch: wthl with exner instead of iexner (spcpl.py:161)", "surface_fluxes_are_the_ifs_fluxes_over_the_surface_density"),
+    18: ("K6 update: qt += (beta - 1) qt, the level mean forgotten (spcpl.py:724)", "variability_nudge_reaches_the_gcm_cloud_amount"),
+    19: ("K6 constantT: dTHL with the opposite sign (spcpl.py:731)", "variability_nudge_reaches_the_gcm_cloud_amount"),
+    20: ("K6: 'significant cloud' threshold 1e-6 instead of 1e-9 (spcpl.py:665)", "variability_nudge_reaches_the_gcm_cloud_amount"),
+    21: ("K6 additive noise subtracted instead of added (spcpl.py:716-719)", "variability_nudge_reaches_the_gcm_cloud_amount"),
 }
 
 

@@ -623,7 +623,7 @@ __global__ __launch_bounds__(BLK, SPC_K1_WAVES) void k_forward(const FwdP<T, FUL
         stg<WT>(&p.f_ps[col], SPC_DIVISOR(T)(p.dt).div(p.factor * SPC_MUT(14, sc_psd - sc_ps, sc_ps - sc_psd)));          // spcpl.py:332
         if constexpr (FULL) {
             if (OPT(ps)) OPT(ps)[col] = sc_ps;
-            if (OPT(rainrate)) OPT(rainrate)[col] = (sc_rain - sc_rl) / p.dt;   // spcpl.py:325
+            if (OPT(rainrate)) OPT(rainrate)[col] = SPC_MUT(23, sc_rl - sc_rain, sc_rain - sc_rl) / p.dt;   // spcpl.py:325
             if (OPT(wthl)) {                                                            // spcpl.py:136-167
                 const T rho = sc_ps / (K<T>::rd * ldg(&p.Tm[col * pitchG + SPC_MUT(15, 0, nG - 1)]));      // spcpl.py:153
                 OPT(wqt)[col] = -(OPT(QLflux)[col] + OPT(QIflux)[col] + OPT(SHflux)[col]) / rho;     // spcpl.py:159
@@ -883,11 +883,11 @@ template <typename T, int NG, int NL, int WT, int BLK = BLOCK, bool PRE = true> 
         } else {
             t_i = qt_i = ql_i = qlw_i = qli_i = u_i = v_i = x;
         }
-        T f_T = ddt.div(p.factor * (t_i - in.tt));                                       // spcpl.py:518
+        T f_T = ddt.div(p.factor * SPC_MUT(24, in.tt - t_i, t_i - in.tt));               // spcpl.py:518
         T f_SH = ddt.div(p.factor * (SPC_MUT(13, qt_i, qt_i - ql_i) - in.sh));                            // spcpl.py:519
         T f_QL = ddt.div(p.factor * (SPC_MUT(3, ql_i, qlw_i) - in.ql));                                    // spcpl.py:520
         T f_QI = ddt.div(p.factor * (qli_i - in.qi));                                    // spcpl.py:521
-        T f_U = ddt.div(p.factor * (u_i - in.u));                                        // spcpl.py:524
+        T f_U = ddt.div(p.factor * (SPC_MUT(22, v_i, u_i) - in.u));                      // spcpl.py:524
         T f_V = ddt.div(p.factor * (v_i - in.v));                                        // spcpl.py:525
         T f_A = ddt.div(p.factor * (in.a_d - in.a));                                     // spcpl.py:526
         if (SPC_MUT(4, k <= start_index, k < start_index)) {  // `f[0:start_index] *= 0` (spcpl.py:527-533): -x -> -0, NaN stays NaN

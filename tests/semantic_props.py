@@ -17,6 +17,7 @@ An implementation is an object with
     les_temperature(gcm, zf, prof)                   -> (pf, t) on LES levels (spcpl.py:408-409)
     surface(gcm, zf, zh, prof)                       -> dict z0m z0h wthl wqt: the surface branch of set_les_forcings (spcpl.py:359-364)
     surface_alone(Ph_s, T_s, QLflux, QIflux, SHflux, TSflux) -> (wthl, wqt): convert_surface_fluxes on its own (spcpl.py:136-167)
+    rainrate(gcm, zf, zh, prof)                      -> [n]: (rain - rain_last) / dt of set_les_forcings (spcpl.py:316-325), prof with Rain, rain_last
     nudge(fields, R, constantT)                      -> dict qt thl beta a qt_std of ONE LES after spcpl.variability_nudge (spcpl.py:613-744);
                                                         fields: qt qsat thl ql [itot x jtot x k], ql_av qt_av presf ql_ref [k]; R [itot x jtot]
 all on NumPy arrays [n_cols x n_lev].
@@ -351,6 +352,41 @@ def prop_variability_nudge_reaches_the_gcm_cloud_amount(impl):
     # without constantT thl is nobody's business
     r2 = impl.nudge(f, R, False)
     assert numpy.array_equal(r2["qt"], r["qt"]) and (r2["thl"] is None or numpy.array_equal(r2["thl"], f["thl"]))
+
+
+# (k) spcpl.py:471-477, 518-525: f_x = factor (x_d at the GCM level - x_gcm) / dt for T, U, V -- a RELAXATION: applied for
+#     dt / factor it lands the GCM level on the LES profile.  With LES profiles LINEAR in height the profile at a GCM height is
+#     known in closed form (the line itself; the end values outside the LES levels, where numpy.interp clamps), whatever the
+#     interpolation code does; three different lines, so that T, U and V cannot stand in for each other.
+#     spcpl.py:316-325: rainrate = (rain - rain_last) / dt.
+def prop_tendencies_relax_the_gcm_towards_the_les_profile(impl):
+    gcm, zf, zh, prof = batch()
+    Zf, _ = heights(gcm)
+    n = gcm["T"].shape[0]
+    lines = {"T": (285.0, -6.5e-3), "U": (3.0, 2.0e-3), "V": (-8.0, 5.0e-4)}
+    p2 = dict(prof)
+    for k, (a, b) in lines.items():
+        p2[k] = numpy.tile(a + b * zf, (n, 1))
+    factor = 0.8
+    r = impl.backward(gcm, zf, zh, p2, factor, DT, False)
+    zc = numpy.clip(Zf, zf[0], zf[-1])
+    for k, (a, b) in lines.items():
+        landed = gcm[k] + r["f_" + k] * DT / factor
+        want = a + b * zc
+        for c in range(n):
+            si = int(r["start_index"][c])
+            tol = 64 * EPS * max(numpy.abs(gcm[k][c]).max(), numpy.abs(want[c]).max())
+            assert numpy.abs(landed[c, si:] - want[c, si:]).max() <= tol, (k, c, numpy.abs(landed[c, si:] - want[c, si:]).max(), tol)
+    # the sign: an LES warmer than the GCM warms it
+    p3 = dict(p2, T=numpy.tile(400.0 + 0 * zf, (n, 1)))
+    r3 = impl.backward(gcm, zf, zh, p3, 1.0, DT, False)
+    for c in range(n):
+        si = int(r3["start_index"][c])
+        assert (r3["f_T"][c, si:] > 0).all()
+    # rain: the amount fallen since the last exchange per unit time (exactly representable numbers: the result is exact)
+    rate = 2.0 ** -10 * (1 + numpy.arange(n) % 4)
+    p4 = dict(prof, rain_last=numpy.full(n, 0.5), Rain=0.5 + DT * rate)
+    assert numpy.array_equal(impl.rainrate(gcm, zf, zh, p4), rate)
 
 
 PROPERTIES = [v for k, v in sorted(globals().items()) if k.startswith("prop_")]

@@ -55,6 +55,12 @@ class HipImpl:
         torch.cuda.synchronize()
         return {k: host(r[k]) for k in ("z0m", "z0h", "wthl", "wqt")}
 
+    def rainrate(self, gcm, zf, zh, prof):
+        e = self.eng
+        r = e.forward(to_dev(gcm, e.device), self._dev(zf), to_dev(prof, e.device), 1.0, sp.DT)
+        torch.cuda.synchronize()
+        return host(r["rainrate"])
+
     def nudge(self, f, R, constantT):
         d = lambda a: self._dev(a[None])                        # noqa: E731   one LES: a batch of one
         qt, thl = d(f["qt"]), d(f["thl"])

@@ -34,6 +34,9 @@ class OracleImpl:
     def surface(self, gcm, zf, zh, prof):
         return orc.forward_batched(gcm, prof, zf, zh, 1.0, sp.DT, couple_surface=True)
 
+    def rainrate(self, gcm, zf, zh, prof):
+        return orc.forward_batched(gcm, prof, zf, zh, 1.0, sp.DT)["rainrate"]
+
     def nudge(self, f, R, constantT):
         from oracle import vnudge_oracle as vo
         r = vo.variability_nudge(f["qt"], f["qsat"], f["ql_av"], f["qt_av"], f["presf"], f["ql_ref"], R, sp.DT, constantT,
@@ -71,6 +74,7 @@ SLIPS = {
     "masking_above_the_les_top": ("searchsorted", lambda a, v, **kw: numpy.searchsorted(a, v, **kw) + 1),
     "reversal_is_index_arithmetic_only": ("interp", lambda x, xp, fp: numpy.interp(x, xp, fp[::-1])),
     "surface_fluxes_are_the_ifs_fluxes_over_the_surface_density": ("cp", 1004. * 1.0000001),        # (a constant of sputils.py:14-20 mistyped)
+    "tendencies_relax_the_gcm_towards_the_les_profile": ("interp", lambda x, xp, fp: fp[numpy.minimum(numpy.searchsorted(xp, x), len(xp) - 1)]),   # the next sample, not the line through two
     "variability_nudge_reaches_the_gcm_cloud_amount": ("vnudge_oracle.exner", lambda p: (p / 1e5) ** (-287.04 / 1004.)),   # iexner for exner, spcpl.py:731
 }
 

@@ -34,6 +34,9 @@ MUTANTS = {
     19: ("K6 constantT: dTHL with the opposite sign (spcpl.py:731)", "variability_nudge_reaches_the_gcm_cloud_amount"),
     20: ("K6: 'significant cloud' threshold 1e-6 instead of 1e-9 (spcpl.py:665)", "variability_nudge_reaches_the_gcm_cloud_amount"),
     21: ("K6 additive noise subtracted instead of added (spcpl.py:716-719)", "variability_nudge_reaches_the_gcm_cloud_amount"),
+    22: ("K3 f_U from the LES v instead of u (spcpl.py:524)", "tendencies_relax_the_gcm_towards_the_les_profile"),
+    23: ("K1 rainrate with the opposite sign (spcpl.py:325)", "tendencies_relax_the_gcm_towards_the_les_profile"),
+    24: ("K3 f_T with the opposite sign (spcpl.py:518)", "tendencies_relax_the_gcm_towards_the_les_profile"),
 }
 
 

@@ -1015,8 +1015,8 @@ template <typename T, int NG, int NL, int WT> __global__ __launch_bounds__(BLOCK
             s[0] = zf_k;
             s[nG] = pf;
         }
-        if (p.Tv) stg<WT>(&p.Tv[g], tt * (T(1) + cc * sh - (ql + qi)));                 // spcpl.py:176
-        if (p.QT) stg<WT>(&p.QT[g], sh + ql + qi);
+        if (p.Tv) stg<WT>(&p.Tv[g], tt * (T(1) + cc * sh - SPC_MUT(25, -(ql + qi), (ql + qi))));   // spcpl.py:176
+        if (p.QT) stg<WT>(&p.QT[g], sh + ql + SPC_MUT(26, T(0), qi));
         if (p.Zf) stg<WT>(&p.Zf[g], zf_k);
         if (p.THL) stg<WT>(&p.THL[g], (tt - div_cp(K<T>::rlv * (ql + qi))) * spc_pow(div_pref0(pf), (-K<T>::rd) / K<T>::cp));
     }
@@ -1024,7 +1024,7 @@ template <typename T, int NG, int NL, int WT> __global__ __launch_bounds__(BLOCK
         for (int e = tid; e < ncol * (nG + 1); e += BLOCK) {
             const int c = e / (nG + 1), k = e - c * (nG + 1);
             const int64_t gh = (col0 + c) * pitchGh;
-            stg<WT>(&p.Zh[gh + k], div_grav(ldg(&p.Zghalf[gh + k]) - ldg(&p.Zghalf[gh + nG])));         // spcpl.py:197
+            stg<WT>(&p.Zh[gh + k], div_grav(ldg(&p.Zghalf[gh + k]) - ldg(&p.Zghalf[gh + SPC_MUT(27, nG - 1, nG)])));   // spcpl.py:197
         }
     }
     if (!les) return;                                                                  // (uniform: no barrier is skipped by part of a workgroup)

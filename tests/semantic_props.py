@@ -17,6 +17,7 @@ An implementation is an object with
     les_temperature(gcm, zf, prof)                   -> (pf, t) on LES levels (spcpl.py:408-409)
     surface(gcm, zf, zh, prof)                       -> dict z0m z0h wthl wqt: the surface branch of set_les_forcings (spcpl.py:359-364)
     surface_alone(Ph_s, T_s, QLflux, QIflux, SHflux, TSflux) -> (wthl, wqt): convert_surface_fluxes on its own (spcpl.py:136-167)
+    gcm_diagnostics(gcm)                             -> dict Tv THL QT Zf Zh on GCM levels (spcpl.py:176, 197-198, 214-215; output_column_conversion :251-267)
     rainrate(gcm, zf, zh, prof)                      -> [n]: (rain - rain_last) / dt of set_les_forcings (spcpl.py:316-325), prof with Rain, rain_last
     nudge(fields, R, constantT)                      -> dict qt thl beta a qt_std of ONE LES after spcpl.variability_nudge (spcpl.py:613-744);
                                                         fields: qt qsat thl ql [itot x jtot x k], ql_av qt_av presf ql_ref [k]; R [itot x jtot]
@@ -387,6 +388,30 @@ def prop_tendencies_relax_the_gcm_towards_the_les_profile(impl):
     rate = 2.0 ** -10 * (1 + numpy.arange(n) % 4)
     p4 = dict(prof, rain_last=numpy.full(n, 0.5), Rain=0.5 + DT * rate)
     assert numpy.array_equal(impl.rainrate(gcm, zf, zh, p4), rate)
+
+
+# (l) spcpl.py:175-176, 197-198, 214-215 (and output_column_conversion, :251-267), the GCM-level diagnostics:
+#     * Tv is the temperature at which DRY air has the density of the mixture: with vapour q_v and condensate q_c per unit mass,
+#       p = rho T (rd (1 - q_v - q_c) + rv q_v) (Dalton: dry air + vapour carry the pressure, the condensate only weighs), so
+#       p / (rd Tv) must be that density;
+#     * QT is all water, THL of an isentropic condensate-free column is its potential temperature;
+#     * Zh / Zf are heights above the SURFACE (the last half level): Zh ends with exactly 0, g Zh + Zg_surface gives the geopotential back.
+def prop_gcm_level_diagnostics_mean_what_their_names_say(impl):
+    gcm, zf, zh, prof = batch()
+    rv = 461.5                                                                    # sputils.py:16
+    d = impl.gcm_diagnostics(gcm)
+    qv, qc, p = gcm["SH"], gcm["QL"] + gcm["QI"], gcm["Pfull"]
+    rho = p / (gcm["T"] * (rd * (1 - qv - qc) + rv * qv))
+    assert (numpy.abs(p / (rd * d["Tv"]) - rho) <= 8 * EPS * rho).all()
+    assert (d["Tv"][qc > 1e-5] < (gcm["T"] * (1 + (rv / rd - 1) * qv))[qc > 1e-5]).all()     # condensate only weighs: it LOWERS Tv
+    assert numpy.array_equal(d["QT"], gcm["SH"] + gcm["QL"] + gcm["QI"])
+    theta = 300.0
+    g = dict(gcm, T=theta * (gcm["Pfull"] / pref0) ** (rd / cp), QL=numpy.zeros_like(gcm["QL"]), QI=numpy.zeros_like(gcm["QI"]))
+    assert (numpy.abs(impl.gcm_diagnostics(g)["THL"] - theta) <= 4 * numpy.spacing(theta)).all()
+    assert (d["Zh"][:, -1] == 0).all() and (numpy.diff(d["Zh"], axis=1) < 0).all()
+    zs = gcm["Zghalf"][:, -1:]
+    assert (numpy.abs(d["Zh"] * grav + zs - gcm["Zghalf"]) <= 4 * EPS * numpy.abs(gcm["Zghalf"]).max()).all()
+    assert (numpy.abs(d["Zf"] * grav + zs - gcm["Zgfull"]) <= 4 * EPS * numpy.abs(gcm["Zgfull"]).max()).all()
 
 
 PROPERTIES = [v for k, v in sorted(globals().items()) if k.startswith("prop_")]

@@ -55,6 +55,12 @@ class HipImpl:
         torch.cuda.synchronize()
         return {k: host(r[k]) for k in ("z0m", "z0h", "wthl", "wqt")}
 
+    def gcm_diagnostics(self, gcm):
+        e = self.eng
+        r = e.diagnostics(to_dev(gcm, e.device))
+        torch.cuda.synchronize()
+        return {k: host(r[k]) for k in ("Tv", "THL", "QT", "Zf", "Zh")}
+
     def rainrate(self, gcm, zf, zh, prof):
         e = self.eng
         r = e.forward(to_dev(gcm, e.device), self._dev(zf), to_dev(prof, e.device), 1.0, sp.DT)

@@ -34,6 +34,10 @@ class OracleImpl:
     def surface(self, gcm, zf, zh, prof):
         return orc.forward_batched(gcm, prof, zf, zh, 1.0, sp.DT, couple_surface=True)
 
+    def gcm_diagnostics(self, gcm):
+        rows = [orc.convert_profiles(orc._row(gcm, i, orc.gcm_vars), numpy.array([10.0, 20.0])) for i in range(gcm["T"].shape[0])]
+        return {k: numpy.stack([r[k] for r in rows]) for k in ("Tv", "THL", "QT", "Zf", "Zh")}
+
     def rainrate(self, gcm, zf, zh, prof):
         return orc.forward_batched(gcm, prof, zf, zh, 1.0, sp.DT)["rainrate"]
 
@@ -75,6 +79,7 @@ SLIPS = {
     "reversal_is_index_arithmetic_only": ("interp", lambda x, xp, fp: numpy.interp(x, xp, fp[::-1])),
     "surface_fluxes_are_the_ifs_fluxes_over_the_surface_density": ("cp", 1004. * 1.0000001),        # (a constant of sputils.py:14-20 mistyped)
     "tendencies_relax_the_gcm_towards_the_les_profile": ("interp", lambda x, xp, fp: fp[numpy.minimum(numpy.searchsorted(xp, x), len(xp) - 1)]),   # the next sample, not the line through two
+    "gcm_level_diagnostics_mean_what_their_names_say": ("rv", 287.04 ** 2 / 461.5),        # rd / rv for rv / rd (spcpl.py:175)
     "variability_nudge_reaches_the_gcm_cloud_amount": ("vnudge_oracle.exner", lambda p: (p / 1e5) ** (-287.04 / 1004.)),   # iexner for exner, spcpl.py:731
 }
 

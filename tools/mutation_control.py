@@ -37,6 +37,9 @@ MUTANTS = {
     22: ("K3 f_U from the LES v instead of u (spcpl.py:524)", "tendencies_relax_the_gcm_towards_the_les_profile"),
     23: ("K1 rainrate with the opposite sign (spcpl.py:325)", "tendencies_relax_the_gcm_towards_the_les_profile"),
     24: ("K3 f_T with the opposite sign (spcpl.py:518)", "tendencies_relax_the_gcm_towards_the_les_profile"),
+    25: ("K5 Tv: the condensate load added instead of subtracted (spcpl.py:176)", "gcm_level_diagnostics_mean_what_their_names_say"),
+    26: ("K5 QT without the ice (spcpl.py:215)", "gcm_level_diagnostics_mean_what_their_names_say"),
+    27: ("K5 Zh above the lowest FULL-level interface instead of the surface (spcpl.py:197)", "gcm_level_diagnostics_mean_what_their_names_say"),
 }
 
 
